@@ -1,0 +1,219 @@
+"""The sequential host/device cores (webp_amd/csrc/vp8l_*_core.h) compiled for the HOST, checked
+against the oracle.  These are the exact sources the GPU kernels include; the host build exists
+only for this test (libvp8l_coretest.so is not the product and the product has no CPU path)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+CSRC = os.path.join(O.ROOT, "webp_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def K():
+    so = os.path.join(CSRC, "libvp8l_coretest.so")
+    subprocess.check_call(["make", "-C", CSRC, "libvp8l_coretest.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(so)
+    L.core_huffman.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.core_write_code_desc.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.core_write_code_desc.restype = C.c_long
+    L.core_prefix_encode.argtypes = [C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
+    L.core_prefix_encode.restype = None
+    for f in ("core_dist_to_code", "core_code_to_dist"):
+        getattr(L, f).argtypes = [C.c_uint32, C.c_uint32]
+        getattr(L, f).restype = C.c_uint32
+    for f in ("core_subtract_green", "core_add_green"):
+        getattr(L, f).argtypes = [C.c_uint32]
+        getattr(L, f).restype = C.c_uint32
+    L.core_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.core_encode.restype = C.c_long
+    L.core_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    return L
+
+
+def core_encode(K, img, w, h):
+    cap = w * h * 5 + 65536
+    buf = np.zeros(cap, dtype=np.uint8)
+    n = K.core_encode(np.ascontiguousarray(img, dtype=np.uint32).ctypes.data, w, h, buf.ctypes.data, cap)
+    return n, buf[: max(n, 0)].tobytes()
+
+
+def core_decode(K, data, w, h):
+    out = np.zeros(w * h, dtype=np.uint32)
+    ww, hh = C.c_uint32(), C.c_uint32()
+    rc = K.core_decode(data, len(data), out.ctypes.data, out.size, C.byref(ww), C.byref(hh))
+    return rc, out, ww.value, hh.value
+
+
+def test_scalar_helpers(K):
+    a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    x, y, z = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    for v in list(range(1, 1300)) + [4096, 65535, 65536, 1 << 20]:
+        K.core_prefix_encode(v, C.byref(a), C.byref(b), C.byref(c))
+        O.lib().ora_prefix_encode(v, C.byref(x), C.byref(y), C.byref(z))
+        assert (a.value, b.value, c.value) == (x.value, y.value, z.value), v
+    for xs in (1, 2, 5, 7, 8, 9, 16, 61, 100, 512, 1920, 3840, 16383):
+        for d in range(1, 1025):
+            assert K.core_dist_to_code(xs, d) == O.lib().ora_dist_to_code(xs, d), (xs, d)
+        for code in range(1, 1145):
+            assert K.core_code_to_dist(xs, code) == O.lib().ora_code_to_dist(xs, code), (xs, code)
+    rng = np.random.default_rng(0)
+    for p in rng.integers(0, 1 << 32, size=500, dtype=np.uint32):
+        arr = np.array([p], dtype=np.uint32)
+        O.lib().ora_subtract_green(arr.ctypes.data, 1)
+        assert K.core_subtract_green(int(p)) == int(arr[0])
+        assert K.core_add_green(int(arr[0])) == int(p)
+
+
+def test_huffman_and_descriptions(K):
+    rng = np.random.default_rng(11)
+    for it in range(400):
+        n = int(rng.choice([40, 68, 256, 280]))
+        kind = it % 6
+        if kind == 0:
+            h = rng.integers(0, 3, size=n)
+        elif kind == 1:
+            h = rng.integers(0, 1 << int(rng.integers(1, 24)), size=n) * (rng.random(n) < rng.random())
+        elif kind == 2:
+            h = rng.geometric(0.01, size=n) * (rng.random(n) < 0.7)
+        elif kind == 3:
+            h = np.round(1e6 * rng.dirichlet(np.full(n, 0.05)))
+        elif kind == 4:
+            h = np.ones(n)
+        else:
+            h = np.zeros(n); h[rng.choice(n, size=int(rng.integers(0, 4)), replace=False)] = 7
+        h = np.ascontiguousarray(h, dtype=np.uint32)
+        maxlen = 32 if n == 68 else 64
+        used, ln, cd = O.huffman_build(h, maxlen)
+        l2 = np.zeros(n, dtype=np.uint8); c2 = np.zeros(n, dtype=np.uint32)
+        u2 = K.core_huffman(h.ctypes.data, n, maxlen, l2.ctypes.data, c2.ctypes.data)
+        assert u2 == used, it
+        if used < 0:
+            continue
+        assert np.array_equal(l2, ln) and np.array_equal(c2, cd), it
+        bits, data = O.write_code(ln)
+        buf = np.zeros(4096, dtype=np.uint8)
+        b2 = K.core_write_code_desc(ln.ctypes.data, n, buf.ctypes.data, buf.size)
+        assert b2 == bits, it
+        assert buf[: len(data)].tobytes() == data, it
+
+
+def test_fibonacci_depth_limit(K):
+    h = np.zeros(280, dtype=np.uint32)
+    a, b = 1, 1
+    for i in range(40):
+        h[i] = a
+        a, b = b, a + b
+    used, _, _ = O.huffman_build(h, 64)
+    l2 = np.zeros(280, dtype=np.uint8); c2 = np.zeros(280, dtype=np.uint32)
+    assert K.core_huffman(h.ctypes.data, 280, 64, l2.ctypes.data, c2.ctypes.data) == used == -3
+
+
+IMAGES = [(3, 64, 64), (4, 64, 64), (5, 64, 64), (5, 61, 19), (3, 1, 1), (3, 2, 1), (4, 1, 5), (3, 130, 3),
+          (4, 200, 40), (5, 97, 33)]
+
+
+@pytest.mark.parametrize("mode,w,h", IMAGES)
+def test_encoder_core_bytes_equal_oracle(K, mode, w, h):
+    img = O.gen_image(mode, w, h, 12345, 200)
+    rc, ref = O.encode(img, w, h)
+    n, got = core_encode(K, img, w, h)
+    assert rc == 0 and n == len(ref)
+    assert got == ref
+
+
+@pytest.mark.parametrize("ncol", [1, 2, 3, 4, 5, 16, 17, 100, 256])
+def test_encoder_core_palette_paths(K, ncol):
+    rng = np.random.default_rng(ncol)
+    pal = rng.integers(0, 1 << 32, size=ncol, dtype=np.uint32)
+    for (w, h) in ((9, 4), (32, 3), (1, 7), (50, 21)):
+        img = pal[rng.integers(0, ncol, size=w * h)]
+        rc, ref = O.encode(img, w, h)
+        n, got = core_encode(K, img, w, h)
+        assert rc == 0 and got == ref, (ncol, w, h)
+    # arithmetic-progression palette: the palette sub-image itself gets long matches
+    pal = (0xFF000000 + np.arange(ncol, dtype=np.uint64) * 0x00010203).astype(np.uint32)
+    img = pal[rng.integers(0, ncol, size=40 * 9)]
+    rc, ref = O.encode(img, 40, 9)
+    n, got = core_encode(K, img, 40, 9)
+    assert rc == 0 and got == ref
+
+
+def test_encoder_core_random_small(K):
+    rng = np.random.default_rng(4)
+    for it in range(40):
+        w, h = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        alpha = int(rng.choice([2, 3, 300, 1 << 20]))
+        img = rng.integers(0, alpha, size=w * h).astype(np.uint32) * np.uint32(0x01020301) + np.uint32(0xFF000000)
+        rc, ref = O.encode(img, w, h)
+        n, got = core_encode(K, img, w, h)
+        assert (rc == 0 and got == ref) or (rc < 0 and n == rc), it
+
+
+@pytest.mark.parametrize("mode,w,h", IMAGES)
+def test_decoder_core_on_encoder_streams(K, mode, w, h):
+    img = O.gen_image(mode, w, h, 999, 200)
+    rc, data = O.encode(img, w, h)
+    assert rc == 0
+    rc, out, ww, hh = core_decode(K, data, w, h)
+    assert rc == 0 and (ww, hh) == (w, h)
+    assert np.array_equal(out, img)
+
+
+EXT = [
+    dict(use_subtract_green=1), dict(predictor_bits=2), dict(predictor_bits=4, use_subtract_green=1),
+    dict(color_bits=3), dict(predictor_bits=3, color_bits=2, use_subtract_green=1, transform_order=1),
+    dict(predictor_bits=2, color_bits=5, use_subtract_green=1, transform_order=2),
+    dict(predictor_bits=2, color_bits=2, transform_order=3), dict(cache_bits=4),
+    dict(cache_bits=11, use_subtract_green=1), dict(meta_bits=2, meta_groups=3),
+    dict(meta_bits=3, meta_groups=7, cache_bits=6, predictor_bits=3, use_subtract_green=1),
+    dict(use_palette=1, cache_bits=3), dict(use_palette=1, meta_bits=2, meta_groups=2),
+    dict(meta_bits=2, meta_groups=100, cache_bits=1),
+]
+
+
+@pytest.mark.parametrize("prm", EXT)
+@pytest.mark.parametrize("shape", [(1, 1), (7, 5), (33, 18), (64, 64), (130, 9)])
+@pytest.mark.parametrize("mode", [3, 4, 5, "rand"])
+def test_decoder_core_on_extended_streams(K, prm, shape, mode):
+    w, h = shape
+    if mode == "rand":
+        img = np.random.default_rng(1).integers(0, 1 << 32, size=w * h, dtype=np.uint32)
+    else:
+        img = O.gen_image(mode, w, h, 5, 200)
+    rc, data = O.encode_ext(img, w, h, **prm)
+    assert rc == 0
+    rc0, ref, _, _ = O.decode(data)
+    rc, out, ww, hh = core_decode(K, data, w, h)
+    assert rc == rc0 == 0
+    assert np.array_equal(out, ref) and np.array_equal(out, img)
+
+
+def test_decoder_core_error_parity_on_corrupt_streams(K):
+    """Same verdict as the oracle on damaged streams, and the same pixels whenever both accept."""
+    rng = np.random.default_rng(77)
+    img = O.gen_image(4, 40, 30, 3, 200)
+    streams = [O.encode(img, 40, 30)[1], O.encode_ext(img, 40, 30, predictor_bits=2, cache_bits=5, meta_bits=2, meta_groups=3)[1],
+               O.encode(O.gen_image(5, 40, 30, 3, 10), 40, 30)[1]]
+    agree = 0
+    for base in streams:
+        for it in range(150):
+            b = bytearray(base)
+            if it % 3 == 0:
+                b = b[: int(rng.integers(9, len(b)))]
+            else:
+                for _ in range(int(rng.integers(1, 4))):
+                    pos = int(rng.integers(9, len(b)))
+                    b[pos] ^= 1 << int(rng.integers(0, 8))
+            b = bytes(b)
+            rc0, ref, w0, h0 = O.decode(b)
+            rc, out, w1, h1 = core_decode(K, b, 40, 30)
+            assert rc == rc0, (it, rc, rc0)
+            if rc == 0:
+                assert np.array_equal(out, ref)
+                agree += 1
+    assert agree > 20

@@ -1,0 +1,333 @@
+// vp8l_enc_core.h -- the small sequential parts of the encoder: Huffman code construction,
+// code-description serialisation, the stream header and the palette sub-image.
+//
+// These run once per image on a few hundred symbols, so they are written as plain sequential
+// host/device code: on the GPU one lane per image executes them out of LDS (k_entropy_header),
+// and the same source compiles for the host so it can be unit-tested without a GPU.
+// The per-pixel work (transforms, match search, parse, histograms, bit emission) lives in the
+// kernels of vp8l_encode.hip.
+#pragma once
+#include "vp8l_common.h"
+
+namespace vp8l {
+
+// LSB-first bit writer into 32-bit words (webp/utils/bit_writer.h:45-64 semantics: bit i of the
+// value goes out first, the tail is zero padded).
+struct BitSink {
+  uint32_t *words;
+  uint64_t acc;
+  uint32_t nacc;
+  uint64_t nwords;
+  VP8L_HD void init(uint32_t *dst) { words = dst; acc = 0; nacc = 0; nwords = 0; }
+  VP8L_HD void put(uint32_t v, uint32_t n) {  // n <= 32
+    if (n == 0) return;
+    const uint64_t m = n >= 32 ? 0xffffffffull : ((1ull << n) - 1ull);
+    acc |= ((uint64_t)v & m) << nacc;
+    nacc += n;
+    if (nacc >= 32) {
+      words[nwords++] = (uint32_t)acc;
+      acc >>= 32;
+      nacc -= 32;
+    }
+  }
+  VP8L_HD uint64_t bits() const { return nwords * 32 + nacc; }
+  // Writes the partial last word zero padded (later writers OR their bits into it).
+  VP8L_HD void flush() { words[nwords] = (uint32_t)acc; }
+};
+
+struct HuffScratch {
+  uint32_t wt[2 * kCodeStride];
+  uint16_t parent[2 * kCodeStride];
+  uint16_t ord[kCodeStride];
+};
+
+VP8L_HD uint32_t bit_reverse(uint32_t v, int len) {
+  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+  v = ((v >> 4) & 0x0f0f0f0fu) | ((v & 0x0f0f0f0fu) << 4);
+  v = ((v >> 8) & 0x00ff00ffu) | ((v & 0x00ff00ffu) << 8);
+  v = (v >> 16) | (v << 16);
+  return v >> (32 - len);
+}
+
+// Code lengths of the reference's Huffman construction (huffman_coding.h:366-419).
+// The reference keeps an array of roots sorted ascending by weight and, after joining the two
+// lightest, re-sorts with a stable sort with the new root in slot 0: the new root therefore
+// lands in front of every root of equal weight, and leaves of equal weight stay in symbol order.
+// That tie rule decides the lengths, so it is reproduced exactly: `ord` is that sorted array.
+// Returns the number of used symbols, or -3 (TooBigCodeLength, huffman_coding.h:410-413).
+// n <= kCodeStride.
+VP8L_HD int huffman_lengths(const uint32_t *histo, int n, int max_len, uint8_t *lengths, HuffScratch &s) {
+  int nn = 0;
+  for (int i = 0; i < n; i++) {
+    lengths[i] = 0;
+    if (histo[i]) { s.wt[nn] = histo[i]; s.parent[nn] = 0xffff; nn++; }
+  }
+  const int used = nn;
+  if (used == 0) return 0;
+  // leaf k is the k-th used symbol; stable insertion sort of leaf ids by weight
+  for (int i = 0; i < used; i++) {
+    int j = i;
+    const uint32_t w = s.wt[i];
+    while (j > 0 && s.wt[s.ord[j - 1]] > w) { s.ord[j] = s.ord[j - 1]; j--; }
+    s.ord[j] = (uint16_t)i;
+  }
+  int head = 0;  // ord[head..used) are the live roots
+  while (used - head > 1) {
+    const int a = s.ord[head], b = s.ord[head + 1];
+    const uint32_t w = s.wt[a] + s.wt[b];
+    s.wt[nn] = w;
+    s.parent[nn] = 0xffff;
+    s.parent[a] = s.parent[b] = (uint16_t)nn;
+    // first live root (past the two removed) that is not lighter than the new one
+    int lo = head + 2, hi = used;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (s.wt[s.ord[mid]] < w) lo = mid + 1; else hi = mid;
+    }
+    for (int i = head + 2; i < lo; i++) s.ord[i - 1] = s.ord[i];
+    s.ord[lo - 1] = (uint16_t)nn;
+    head++;
+    nn++;
+  }
+  int maxl = 0, leaf = 0;
+  for (int i = 0; i < n; i++) {
+    if (!histo[i]) continue;
+    int d = 0;
+    for (int v = leaf; s.parent[v] != 0xffff; v = s.parent[v]) d++;
+    if (used == 1) d = 1;  // a lone symbol gets length 1 (huffman_coding.h:398-402)
+    lengths[i] = (uint8_t)(d > 255 ? 255 : d);
+    if (d > maxl) maxl = d;
+    leaf++;
+  }
+  if (maxl > max_len || maxl > kSaneCodeLen) return -3;
+  return used;
+}
+
+// Canonical codes in symbol order (huffman_coding.cpp:8-49), bit-reversed for the LSB-first
+// writer (huffman_coding.h:356-363,415-418).  Lengths <= 32.
+VP8L_HD void canonical_reversed_codes(const uint8_t *lengths, int n, uint32_t *codes) {
+  uint32_t count[kSaneCodeLen + 2], next[kSaneCodeLen + 2];
+  for (int l = 0; l <= kSaneCodeLen + 1; l++) count[l] = 0;
+  int maxl = 0;
+  for (int i = 0; i < n; i++) { count[lengths[i]]++; if (lengths[i] > maxl) maxl = lengths[i]; }
+  count[0] = 0;
+  uint32_t cur = 0;
+  next[0] = 0;
+  for (int l = 1; l <= maxl; l++) { cur = (cur + count[l - 1]) << 1; next[l] = cur; }
+  for (int i = 0; i < n; i++) codes[i] = lengths[i] ? bit_reverse(next[lengths[i]]++, lengths[i]) : 0;
+}
+
+struct DescScratch {
+  HuffScratch huff;
+  uint8_t rle_sym[kCodeStride + 8];
+  uint8_t rle_extra[kCodeStride + 8];
+  uint32_t cl_histo[kNumClSyms];
+  uint32_t cl_code[kNumClSyms];
+  uint8_t cl_len[kNumClSyms];
+};
+
+// Run-length form of a code-length array (huffman_io.h:226-326).
+VP8L_HD int rle_code_lengths(const uint8_t *lengths, int n, uint8_t *sym, uint8_t *extra) {
+  int k = 0, prev = 8;
+  int i = 0;
+  while (i < n) {
+    const int v = lengths[i];
+    int j = i + 1;
+    while (j < n && lengths[j] == v) j++;
+    int reps = j - i;
+    i = j;
+    if (v == 0) {
+      while (reps >= 139) { sym[k] = kClZero138; extra[k++] = 127; reps -= 138; }
+      if (reps >= 11) { sym[k] = kClZero138; extra[k++] = (uint8_t)(reps - 11); }
+      else if (reps >= 3) { sym[k] = kClZero11; extra[k++] = (uint8_t)(reps - 3); }
+      else for (; reps > 0; reps--) { sym[k] = 0; extra[k++] = 0; }
+    } else {
+      if (prev != v) { sym[k] = (uint8_t)v; extra[k++] = 0; reps--; }
+      while (reps >= 7) { sym[k] = kClRepeat; extra[k++] = 3; reps -= 6; }
+      if (reps >= 3) { sym[k] = kClRepeat; extra[k++] = (uint8_t)(reps - 3); }
+      else for (; reps > 0; reps--) { sym[k] = (uint8_t)v; extra[k++] = 0; }
+      prev = v;
+    }
+  }
+  return k;
+}
+
+// One code description (huffman_io.h:331-410).  Returns 0 or -3.
+VP8L_HD int write_code_desc(BitSink &bw, const uint8_t *lengths, int n, DescScratch &s) {
+  int count = 0;
+  uint32_t first[2] = {0, 0};
+  for (int i = 0; i < n && count <= 2; i++)
+    if (lengths[i]) { if (count < 2) first[count] = (uint32_t)i; count++; }
+  if (count == 0) { bw.put(1, 4); return 0; }  // bits 1,0,0,0 (huffman_io.h:387-392)
+  if (count <= 2 && first[0] < 256 && first[1] < 256) {
+    bw.put(1, 1);
+    bw.put((uint32_t)(count - 1), 1);
+    if (first[0] <= 1) { bw.put(0, 1); bw.put(first[0], 1); }
+    else { bw.put(1, 1); bw.put(first[0], 8); }
+    if (count == 2) bw.put(first[1], 8);
+    return 0;
+  }
+  bw.put(0, 1);
+  const int nitems = rle_code_lengths(lengths, n, s.rle_sym, s.rle_extra);
+  for (int i = 0; i < kNumClSyms; i++) s.cl_histo[i] = 0;
+  for (int i = 0; i < nitems; i++) s.cl_histo[s.rle_sym[i]]++;
+  const int used = huffman_lengths(s.cl_histo, kNumClSyms, kMaxClCodeLen, s.cl_len, s.huff);
+  if (used < 0) return used;
+  canonical_reversed_codes(s.cl_len, kNumClSyms, s.cl_code);
+  int nwrite = kNumClSyms;
+  while (nwrite > 4 && s.cl_len[cl_order(nwrite - 1)] == 0) nwrite--;
+  bw.put((uint32_t)(nwrite - 4), kClCountBits);
+  for (int i = 0; i < nwrite; i++) bw.put(s.cl_len[cl_order(i)], kClLenBits);
+  bw.put(0, 1);  // no max_symbol (huffman_io.h:358)
+  for (int i = 0; i < nitems; i++) {
+    const int sy = s.rle_sym[i];
+    // With a single used code-length symbol its length is 1 and one 0 bit per item is written,
+    // although the reference reader consumes none (huffman_io.h:363 vs huffman_coding.h:207-214):
+    // kept byte-identical; the reference cannot decode such a stream either.
+    bw.put(s.cl_code[sy], s.cl_len[sy]);
+    if (sy == kClRepeat) bw.put(s.rle_extra[i], 2);
+    else if (sy == kClZero11) bw.put(s.rle_extra[i], 3);
+    else if (sy == kClZero138) bw.put(s.rle_extra[i], 7);
+  }
+  return 0;
+}
+
+// Encoder-side tables of one image: 5 codes, stride kCodeStride.
+struct CodeTables {
+  uint32_t code[kNumCodes * kCodeStride];
+  uint8_t len[kNumCodes * kCodeStride];
+  uint32_t used[kNumCodes];  // number of symbols with non-zero count
+};
+
+// Builds the five codes from the five histograms and writes their descriptions
+// (vp8l.h:536-540).  Returns 0 or -3.
+VP8L_HD int build_and_write_codes(BitSink &bw, const uint32_t *histo /*[5*kCodeStride]*/, CodeTables &t,
+                                  DescScratch &s) {
+  for (int c = 0; c < kNumCodes; c++) {
+    const int n = alphabet_size(c);
+    uint8_t *len = t.len + c * kCodeStride;
+    const int used = huffman_lengths(histo + c * kCodeStride, n, kMaxCodeLen, len, s.huff);
+    if (used < 0) return used;
+    t.used[c] = (uint32_t)used;
+    canonical_reversed_codes(len, n, t.code + c * kCodeStride);
+    const int rc = write_code_desc(bw, len, n, s);
+    if (rc < 0) return rc;
+  }
+  return 0;
+}
+
+// Greedy parse of a SMALL array (the palette, n <= 256) with the reference's rules
+// (lz77.h:28-93): window 1024, match length <= min(distance, 128, remaining), shortest match 1,
+// farthest candidate wins ties, the final element is always a literal.  adv[p] = match length at
+// p (0 = literal), dst[p] = its distance.  O(n^2): next_mis[d] tracks, while p runs backwards,
+// the first position q >= p with data[q-d] != data[q].
+struct SmallLzScratch {
+  uint16_t next_mis[kMaxPalette + 1];
+  uint16_t len[kMaxPalette];
+  uint16_t dist[kMaxPalette];
+};
+
+VP8L_HD void small_best_matches(const uint32_t *data, int n, SmallLzScratch &s) {
+  for (int d = 0; d <= n; d++) s.next_mis[d] = (uint16_t)n;
+  for (int p = n - 1; p >= 0; p--) {
+    int best = 0, bestd = 0;
+    const int rem = n - p < (int)kMaxLen ? n - p : (int)kMaxLen;
+    for (int d = 1; d <= p && d <= (int)kWindow; d++) {
+      if (data[p - d] != data[p]) s.next_mis[d] = (uint16_t)p;
+      int l = s.next_mis[d] - p;
+      if (l > d) l = d;
+      if (l > rem) l = rem;
+      if (l > 0 && l >= best) { best = l; bestd = d; }
+    }
+    if (rem <= 1) best = 0;
+    s.len[p] = (uint16_t)best;
+    s.dist[p] = (uint16_t)bestd;
+  }
+}
+
+struct SubImageScratch {
+  DescScratch desc;
+  SmallLzScratch lz;
+  CodeTables tables;
+  uint32_t histo[kNumCodes * kCodeStride];
+  uint32_t delta[kMaxPalette];
+};
+
+// Token bits of one position (vp8l.h:545-583).  Emits through `put(value, nbits)`.
+template <class Put>
+VP8L_HD void emit_token(Put &&put, const CodeTables &t, uint32_t pixel, uint32_t len, uint32_t dist, uint32_t xsize) {
+  if (len == 0) {
+    const uint32_t g = (pixel >> 8) & 0xff, r = (pixel >> 16) & 0xff, b = pixel & 0xff, a = pixel >> 24;
+    if (t.used[kGreen] > 1) put(t.code[kGreen * kCodeStride + g], t.len[kGreen * kCodeStride + g]);
+    if (t.used[kRed] > 1) put(t.code[kRed * kCodeStride + r], t.len[kRed * kCodeStride + r]);
+    if (t.used[kBlue] > 1) put(t.code[kBlue * kCodeStride + b], t.len[kBlue * kCodeStride + b]);
+    if (t.used[kAlpha] > 1) put(t.code[kAlpha * kCodeStride + a], t.len[kAlpha * kCodeStride + a]);
+  } else {
+    uint32_t sym, nb, eb;
+    prefix_encode(len, sym, nb, eb);
+    put(t.code[kGreen * kCodeStride + 256 + sym], t.len[kGreen * kCodeStride + 256 + sym]);  // always written (vp8l.h:570)
+    if (nb) put(eb, nb);
+    prefix_encode(dist_to_code(xsize, dist), sym, nb, eb);
+    if (t.used[kDist] > 1) put(t.code[kDist * kCodeStride + sym], t.len[kDist * kCodeStride + sym]);
+    if (nb) put(eb, nb);
+  }
+}
+
+VP8L_HD void histo_token(uint32_t *histo, uint32_t pixel, uint32_t len, uint32_t dist, uint32_t xsize) {
+  if (len == 0) {
+    histo[kGreen * kCodeStride + ((pixel >> 8) & 0xff)]++;
+    histo[kRed * kCodeStride + ((pixel >> 16) & 0xff)]++;
+    histo[kBlue * kCodeStride + (pixel & 0xff)]++;
+    histo[kAlpha * kCodeStride + (pixel >> 24)]++;
+  } else {
+    uint32_t sym, nb, eb;
+    prefix_encode(len, sym, nb, eb);
+    histo[kGreen * kCodeStride + 256 + sym]++;
+    prefix_encode(dist_to_code(xsize, dist), sym, nb, eb);
+    histo[kDist * kCodeStride + sym]++;
+  }
+}
+
+// WriteEntropyCodedImage for the palette (vp8l.h:477-510, called from :457 with xsize = n, ysize = 1).
+VP8L_HD int write_small_coded_image(BitSink &bw, const uint32_t *data, int n, SubImageScratch &s) {
+  bw.put(0, 1);  // no colour cache
+  small_best_matches(data, n, s.lz);
+  for (int i = 0; i < kNumCodes * kCodeStride; i++) s.histo[i] = 0;
+  for (int p = 0; p < n; p += s.lz.len[p] ? s.lz.len[p] : 1) histo_token(s.histo, data[p], s.lz.len[p], s.lz.dist[p], (uint32_t)n);
+  const int rc = build_and_write_codes(bw, s.histo, s.tables, s.desc);
+  if (rc < 0) return rc;
+  for (int p = 0; p < n; p += s.lz.len[p] ? s.lz.len[p] : 1)
+    emit_token([&](uint32_t v, uint32_t nb) { bw.put(v, nb); }, s.tables, data[p], s.lz.len[p], s.lz.dist[p], (uint32_t)n);
+  return 0;
+}
+
+// Everything in front of the main image's five code descriptions:
+// write_info (vp8l.h:460-467), the transform (subtract green :417-418, or colour indexing with its
+// delta-coded palette :451-457), "no more transforms" (:609), "no cache", "no meta codes" (:512-513).
+VP8L_HD int write_stream_prefix(BitSink &bw, uint32_t w, uint32_t h, const uint32_t *palette, uint32_t ncolors,
+                                SubImageScratch &s) {
+  bw.put(0, 32);
+  bw.put(0x2f, 8);
+  bw.put(w - 1, 14);
+  bw.put(h - 1, 14);
+  bw.put(0, 1);
+  bw.put(0, 3);
+  bw.put(1, 1);
+  if (ncolors == 0) {
+    bw.put(2, 2);
+  } else {
+    bw.put(3, 2);
+    bw.put(ncolors - 1, 8);
+    s.delta[0] = palette[0];
+    for (uint32_t i = 1; i < ncolors; i++) s.delta[i] = px_sub(palette[i], palette[i - 1]);  // vp8l.h:455-456
+    const int rc = write_small_coded_image(bw, s.delta, (int)ncolors, s);
+    if (rc < 0) return rc;
+  }
+  bw.put(0, 1);
+  bw.put(0, 1);
+  bw.put(0, 1);
+  return 0;
+}
+
+}  // namespace vp8l
