@@ -1,0 +1,124 @@
+/*
+ * vp8l_amd.h -- C ABI of the MI355X VP8L (lossless WebP, reference dialect) codec core.
+ *
+ * This is the drop-in boundary for the reference's webp/vp8l, webp/lz77 and
+ * webp/huffman_coding subsystems (RuslanKutdusov/WebP).  Plain pointers and sizes only.
+ * Streams are exactly the bytes the reference's utils::BitWriter holds after
+ * VP8_LOSSLESS_ENCODER's constructor (vp8l.h:585-612): four zero "length" bytes, 0x2F, the
+ * 14+14+1+3 bit header, transforms, codes, pixels -- no RIFF container.
+ *
+ * All work runs on the GPU (gfx950).  There is no CPU fallback: without a usable device
+ * every entry point returns VP8L_ERR_NO_DEVICE.
+ */
+#ifndef VP8L_AMD_H_
+#define VP8L_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One code per reference exception type (webp/exception/exception.h:14-153). */
+typedef enum {
+  VP8L_OK = 0,
+  VP8L_ERR_INVALID_ARGB = -1,        /* exception::InvalidARGBImage   vp8l.h:587-588            */
+  VP8L_ERR_TOO_BIG_ARGB = -2,        /* exception::TooBigARGBImage    vp8l.h:589-590            */
+  VP8L_ERR_TOO_BIG_CODE_LENGTH = -3, /* exception::TooBigCodeLength   huffman_coding.h:410-413  */
+  VP8L_ERR_UNSUPPORTED_VP8 = -4,     /* exception::UnsupportedVP8     vp8l.h:87-88              */
+  VP8L_ERR_INVALID_VP8L = -5,        /* exception::InvalidVP8L        vp8l.h:107-108,236-237; transform.h:185-186 */
+  VP8L_ERR_INVALID_HUFFMAN = -6,     /* exception::InvalidHuffman     huffman_io.h:105,140,184  */
+  VP8L_ERR_NO_DEVICE = -7,           /* no gfx950 device / HIP runtime failure at start-up      */
+  VP8L_ERR_NO_MEMORY = -8,           /* exception::MemoryAllocationException                    */
+  VP8L_ERR_HIP = -9,                 /* a HIP call failed; vp8l_last_error() has the text       */
+  VP8L_ERR_BAD_ARGUMENT = -10,
+  VP8L_ERR_WORKSPACE = -11           /* internal: decode workspace too small (retried inside)   */
+} vp8l_status;
+
+/* Replaces huffman_io::init_array() (huffman_io.h:53-65), which the reference's main() must call
+ * before any codec use (webp.cpp:128).  The code-length order table is a compile-time constant
+ * here, so this only checks that a device is usable; calling it is optional.
+ * Returns the number of usable devices (>= 1) or VP8L_ERR_NO_DEVICE. */
+int vp8l_init(void);
+
+const char *vp8l_status_string(int status);
+const char *vp8l_last_error(void); /* thread-local text of the last HIP failure */
+
+/* ---- one image, host memory ------------------------------------------------------------
+ * vp8l_encode replaces `VP8_LOSSLESS_ENCODER(argb, width, height)` + `get_bit_writer()`
+ * (vp8l.h:585-615).  argb: width*height pixels 0xAARRGGBB, borrowed.  *out is allocated by the
+ * library (release with vp8l_free) and holds *out_len bytes.  flags must be 0. */
+int vp8l_encode(const uint32_t *argb, uint32_t width, uint32_t height, uint8_t **out, size_t *out_len,
+                uint32_t flags);
+
+/* vp8l_decode replaces `VP8_LOSSLESS_DECODER(data, data_length, argb_image)` + image_width()/
+ * image_height() (vp8l.h:330-351).  data = the bytes that follow the "VP8L" fourcc in a .webp
+ * file (webp.h:61-66).  *argb is allocated by the library (vp8l_free), width*height pixels. */
+int vp8l_decode(const uint8_t *data, size_t len, uint32_t **argb, uint32_t *width, uint32_t *height);
+
+/* ReadInfo (vp8l.h:83-94) on the host: dimensions from the first 9 bytes. */
+int vp8l_get_info(const uint8_t *data, size_t len, uint32_t *width, uint32_t *height);
+
+void vp8l_free(void *p);
+
+/* ---- batches, host memory ----------------------------------------------------------------
+ * n independent images on one device (device < 0: current device).  Per-image results in
+ * status[i]; the return value is VP8L_OK when the batch ran (even if single images failed). */
+int vp8l_encode_batch(int device, size_t n, const uint32_t *const *argb, const uint32_t *width,
+                      const uint32_t *height, uint8_t **out, size_t *out_len, int *status);
+int vp8l_decode_batch(int device, size_t n, const uint8_t *const *data, const size_t *len, uint32_t **argb,
+                      uint32_t *width, uint32_t *height, int *status);
+
+/* ---- batches, device memory (pipelines, benchmarks) ---------------------------------------
+ * The reference has no counterpart: it is single-image, host-only.  These are the batch forms
+ * with inputs and outputs resident in HBM.  A context owns its workspace and one HIP stream;
+ * calls on one context are serialised, different contexts are independent. */
+typedef struct vp8l_encoder vp8l_encoder;
+typedef struct vp8l_decoder vp8l_decoder;
+
+int vp8l_encoder_create(int device, vp8l_encoder **enc);
+void vp8l_encoder_destroy(vp8l_encoder *enc);
+/* Upper bound of one stream's size in bytes (what to reserve per image in d_out). */
+size_t vp8l_encode_bound(uint32_t width, uint32_t height);
+/* d_argb[i]: device pointer to width[i]*height[i] pixels (host array of device pointers).
+ * d_out: device buffer of out_cap bytes, 256-byte aligned.  Stream i is written at
+ * d_out + out_offset[i] (out_offset is an OUTPUT, host array) with out_len[i] bytes. */
+int vp8l_encoder_encode_device(vp8l_encoder *enc, size_t n, const uint32_t *const *d_argb, const uint32_t *width,
+                               const uint32_t *height, uint8_t *d_out, size_t out_cap, size_t *out_offset,
+                               size_t *out_len, int *status);
+
+/* Stage outputs of the LAST encode call on this context, for parity checks of the intermediate
+ * planes (copied to host memory).  what: */
+enum {
+  VP8L_STAGE_RESIDUAL = 0, /* transformed (subtract-green / indexed+bundled) pixels, uint32 x M        */
+  VP8L_STAGE_MATCH = 1,    /* per position: length | distance<<8 | parse_flag<<31, uint32 x M          */
+  VP8L_STAGE_HISTO = 2,    /* 5 x 280 uint32 (GREEN, RED, BLUE, ALPHA, DIST; unused tail zero)           */
+  VP8L_STAGE_CODELEN = 3,  /* 5 x 280 uint8 code lengths                                                 */
+  VP8L_STAGE_INFO = 4      /* uint32[4]: ncolors (0 = subtract-green path), bundling bits, xsize, M     */
+};
+long vp8l_encoder_fetch_stage(vp8l_encoder *enc, size_t image, int what, void *host_buf, size_t cap_bytes);
+
+int vp8l_decoder_create(int device, vp8l_decoder **dec);
+void vp8l_decoder_destroy(vp8l_decoder *dec);
+/* d_data[i]: device pointer to stream i (len[i] bytes; 4-byte aligned).  width/height: from
+ * vp8l_get_info.  d_argb[i]: device pointer receiving width[i]*height[i] pixels. */
+int vp8l_decoder_decode_device(vp8l_decoder *dec, size_t n, const uint8_t *const *d_data, const size_t *len,
+                               const uint32_t *width, const uint32_t *height, uint32_t *const *d_argb, int *status);
+
+/* Seconds spent in the device part of the last call on the context (HIP events on the
+ * context's stream), and per-kernel-stage seconds for the encoder
+ * (stage order: palette, transform, match, parse, histogram, header, bitcount+scan, emit). */
+double vp8l_encoder_last_device_seconds(const vp8l_encoder *enc);
+int vp8l_encoder_last_stage_seconds(const vp8l_encoder *enc, double *seconds, int cap);
+double vp8l_decoder_last_device_seconds(const vp8l_decoder *dec);
+
+/* Synthetic benchmark/test images generated on the device (seeded LCG, same definitions as the
+ * survey's known-answer images: mode 3 photo-like, 4 graphics, 5 palette with ncolors). */
+int vp8l_generate_device(int device, int mode, uint32_t width, uint32_t height, uint32_t seed, uint32_t ncolors,
+                         uint32_t *d_argb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VP8L_AMD_H_ */

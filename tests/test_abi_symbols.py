@@ -1,0 +1,48 @@
+"""CPU-only: the shipped library loads and exports every function include/vp8l_amd.h declares.
+No codec call is made here (there is no GPU in the build container and no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import webp_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "vp8l_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vp8l_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_functions() == sorted(webp_amd.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(webp_amd.LIB_PATH), "build the HIP library first (__graft_entry__.build())"
+    L = C.CDLL(webp_amd.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(L, name), name
+
+
+def test_get_info_is_host_only():
+    # ReadInfo on the host: 9 header bytes
+    hdr = bytes([0, 0, 0, 0, 0x2F]) + (((100 - 1) | ((50 - 1) << 14)).to_bytes(4, "little"))
+    assert webp_amd.get_info(hdr) == (100, 50)
+    try:
+        webp_amd.get_info(b"\0\0\0\0\x2e\0\0\0\0")
+        assert False
+    except webp_amd.Vp8lError as e:
+        assert e.name == "UnsupportedVP8"
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        return
+    try:
+        webp_amd.encode([0xFF000000], 1, 1)
+        assert False, "encode must not succeed without a GPU"
+    except webp_amd.Vp8lError as e:
+        assert e.name == "NoDevice"

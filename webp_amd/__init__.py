@@ -1,0 +1,294 @@
+"""webp_amd -- MI355X (gfx950) VP8L codec core: thin ctypes binding over the C ABI
+(include/vp8l_amd.h, built as webp_amd/csrc/libvp8l_amd.so).
+
+The codec itself is HIP code; this module only marshals pointers.  There is no CPU fallback:
+importing works anywhere, but every call fails with Vp8lError(NO_DEVICE) without a gfx950 GPU,
+and loading fails loudly if the library has not been built.
+
+Names follow the reference's exception types (webp/exception/exception.h) so parity tests read
+like calls into the reference: InvalidARGBImage, TooBigARGBImage, TooBigCodeLength,
+UnsupportedVP8, InvalidVP8L, InvalidHuffman.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvp8l_amd.so")
+
+OK = 0
+STATUS_NAMES = {
+    0: "OK", -1: "InvalidARGBImage", -2: "TooBigARGBImage", -3: "TooBigCodeLength", -4: "UnsupportedVP8",
+    -5: "InvalidVP8L", -6: "InvalidHuffman", -7: "NoDevice", -8: "MemoryAllocationException", -9: "HipError",
+    -10: "BadArgument", -11: "Workspace",
+}
+STAGE_RESIDUAL, STAGE_MATCH, STAGE_HISTO, STAGE_CODELEN, STAGE_INFO = range(5)
+ENCODE_STAGES = ("palette", "transform", "match", "parse", "histogram", "header", "bitcount_scan", "emit")
+
+
+class Vp8lError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        self.name = STATUS_NAMES.get(status, "status %d" % status)
+        detail = ""
+        if status in (-7, -9):
+            try:
+                detail = ": " + lib().vp8l_last_error().decode()
+            except Exception:  # pragma: no cover
+                pass
+        super().__init__("%s%s%s" % (self.name, " in " + where if where else "", detail))
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C ABI.  Raises if the HIP library was not built (never falls back)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        pp_void = C.POINTER(C.c_void_p)
+        L.vp8l_init.restype = C.c_int
+        L.vp8l_status_string.argtypes = [C.c_int]
+        L.vp8l_status_string.restype = C.c_char_p
+        L.vp8l_last_error.restype = C.c_char_p
+        L.vp8l_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, pp_void, C.POINTER(C.c_size_t), C.c_uint32]
+        L.vp8l_decode.argtypes = [C.c_char_p, C.c_size_t, pp_void, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.vp8l_get_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.vp8l_free.argtypes = [C.c_void_p]
+        L.vp8l_free.restype = None
+        L.vp8l_encode_batch.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vp8l_decode_batch.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vp8l_encoder_create.argtypes = [C.c_int, pp_void]
+        L.vp8l_encoder_destroy.argtypes = [C.c_void_p]
+        L.vp8l_encoder_destroy.restype = None
+        L.vp8l_encode_bound.argtypes = [C.c_uint32, C.c_uint32]
+        L.vp8l_encode_bound.restype = C.c_size_t
+        L.vp8l_encoder_encode_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vp8l_encoder_fetch_stage.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+        L.vp8l_encoder_fetch_stage.restype = C.c_long
+        L.vp8l_encoder_last_device_seconds.argtypes = [C.c_void_p]
+        L.vp8l_encoder_last_device_seconds.restype = C.c_double
+        L.vp8l_encoder_last_stage_seconds.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.vp8l_decoder_create.argtypes = [C.c_int, pp_void]
+        L.vp8l_decoder_destroy.argtypes = [C.c_void_p]
+        L.vp8l_decoder_destroy.restype = None
+        L.vp8l_decoder_decode_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]
+        L.vp8l_decoder_last_device_seconds.argtypes = [C.c_void_p]
+        L.vp8l_decoder_last_device_seconds.restype = C.c_double
+        L.vp8l_generate_device.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = (
+    "vp8l_init", "vp8l_status_string", "vp8l_last_error", "vp8l_encode", "vp8l_decode", "vp8l_get_info", "vp8l_free",
+    "vp8l_encode_batch", "vp8l_decode_batch", "vp8l_encoder_create", "vp8l_encoder_destroy", "vp8l_encode_bound",
+    "vp8l_encoder_encode_device", "vp8l_encoder_fetch_stage", "vp8l_decoder_create", "vp8l_decoder_destroy",
+    "vp8l_decoder_decode_device", "vp8l_encoder_last_device_seconds", "vp8l_encoder_last_stage_seconds",
+    "vp8l_decoder_last_device_seconds", "vp8l_generate_device",
+)
+
+
+def init():
+    rc = lib().vp8l_init()
+    if rc < 0:
+        raise Vp8lError(rc, "vp8l_init")
+    return rc
+
+
+# ------------------------------------------------------------------ host-memory forms
+def encode(argb, width, height):
+    """VP8_LOSSLESS_ENCODER(argb, width, height).get_bit_writer() -> stream bytes (vp8l.h:585-615)."""
+    a = None if argb is None else np.ascontiguousarray(argb, dtype=np.uint32)
+    out = C.c_void_p()
+    n = C.c_size_t()
+    rc = lib().vp8l_encode(a.ctypes.data if a is not None and a.size else None, width, height, C.byref(out), C.byref(n), 0)
+    if rc != OK:
+        raise Vp8lError(rc, "vp8l_encode")
+    data = C.string_at(out.value, n.value)
+    lib().vp8l_free(out)
+    return data
+
+
+def decode(data):
+    """VP8_LOSSLESS_DECODER(data, len, argb) -> (argb uint32[w*h], width, height) (vp8l.h:330-351)."""
+    out = C.c_void_p()
+    w, h = C.c_uint32(), C.c_uint32()
+    rc = lib().vp8l_decode(data, len(data), C.byref(out), C.byref(w), C.byref(h))
+    if rc != OK:
+        raise Vp8lError(rc, "vp8l_decode")
+    arr = np.frombuffer(C.string_at(out.value, w.value * h.value * 4), dtype=np.uint32).copy()
+    lib().vp8l_free(out)
+    return arr, w.value, h.value
+
+
+def get_info(data):
+    w, h = C.c_uint32(), C.c_uint32()
+    rc = lib().vp8l_get_info(data, len(data), C.byref(w), C.byref(h))
+    if rc != OK:
+        raise Vp8lError(rc, "vp8l_get_info")
+    return w.value, h.value
+
+
+def encode_batch(images, device=-1):
+    """images: list of (argb, w, h).  Returns list of (status, bytes)."""
+    n = len(images)
+    arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a, _, _ in images]
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
+    ws = (C.c_uint32 * n)(*[w for _, w, _ in images])
+    hs = (C.c_uint32 * n)(*[h for _, _, h in images])
+    outs = (C.c_void_p * n)()
+    lens = (C.c_size_t * n)()
+    status = (C.c_int * n)()
+    rc = lib().vp8l_encode_batch(device, n, ptrs, ws, hs, outs, lens, status)
+    if rc != OK:
+        raise Vp8lError(rc, "vp8l_encode_batch")
+    res = []
+    for i in range(n):
+        if status[i] == OK:
+            res.append((OK, C.string_at(outs[i], lens[i])))
+            lib().vp8l_free(outs[i])
+        else:
+            res.append((status[i], b""))
+    return res
+
+
+def decode_batch(streams, device=-1):
+    """streams: list of bytes.  Returns list of (status, argb | None, w, h)."""
+    n = len(streams)
+    bufs = [C.create_string_buffer(s, len(s)) for s in streams]
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    lens = (C.c_size_t * n)(*[len(s) for s in streams])
+    outs = (C.c_void_p * n)()
+    ws = (C.c_uint32 * n)()
+    hs = (C.c_uint32 * n)()
+    status = (C.c_int * n)()
+    rc = lib().vp8l_decode_batch(device, n, ptrs, lens, outs, ws, hs, status)
+    if rc != OK:
+        raise Vp8lError(rc, "vp8l_decode_batch")
+    res = []
+    for i in range(n):
+        if status[i] == OK:
+            arr = np.frombuffer(C.string_at(outs[i], ws[i] * hs[i] * 4), dtype=np.uint32).copy()
+            lib().vp8l_free(outs[i])
+            res.append((OK, arr, ws[i], hs[i]))
+        else:
+            res.append((status[i], None, ws[i], hs[i]))
+    return res
+
+
+# ------------------------------------------------------------------ device-memory forms
+class Encoder:
+    """Batch encoder context (vp8l_encoder_*).  Device pointers are plain integers, e.g.
+    torch.Tensor.data_ptr() of uint8/int32 CUDA tensors."""
+
+    def __init__(self, device=-1):
+        self._h = C.c_void_p()
+        rc = lib().vp8l_encoder_create(device, C.byref(self._h))
+        if rc != OK:
+            raise Vp8lError(rc, "vp8l_encoder_create")
+
+    def close(self):
+        if self._h:
+            lib().vp8l_encoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    @staticmethod
+    def bound(w, h):
+        return lib().vp8l_encode_bound(w, h)
+
+    def encode_device(self, d_argb_ptrs, widths, heights, d_out_ptr, out_cap):
+        """Returns (offsets, lengths, status) as numpy arrays."""
+        n = len(d_argb_ptrs)
+        ptrs = (C.c_void_p * n)(*d_argb_ptrs)
+        ws = (C.c_uint32 * n)(*widths)
+        hs = (C.c_uint32 * n)(*heights)
+        off = (C.c_size_t * n)()
+        lens = (C.c_size_t * n)()
+        status = (C.c_int * n)()
+        rc = lib().vp8l_encoder_encode_device(self._h, n, ptrs, ws, hs, d_out_ptr, out_cap, off, lens, status)
+        if rc != OK:
+            raise Vp8lError(rc, "vp8l_encoder_encode_device")
+        return np.array(off[:], dtype=np.uint64), np.array(lens[:], dtype=np.uint64), np.array(status[:], dtype=np.int32)
+
+    def fetch_stage(self, image, what):
+        info = np.zeros(4, dtype=np.uint32)
+        rc = lib().vp8l_encoder_fetch_stage(self._h, image, STAGE_INFO, info.ctypes.data, info.nbytes)
+        if rc < 0:
+            raise Vp8lError(int(rc), "vp8l_encoder_fetch_stage")
+        if what == STAGE_INFO:
+            return dict(ncolors=int(info[0]), bits=int(info[1]), xsize=int(info[2]), M=int(info[3]))
+        if what in (STAGE_RESIDUAL, STAGE_MATCH):
+            buf = np.zeros(int(info[3]), dtype=np.uint32)
+        elif what == STAGE_HISTO:
+            buf = np.zeros(5 * 280, dtype=np.uint32)
+        else:
+            buf = np.zeros(5 * 280, dtype=np.uint8)
+        rc = lib().vp8l_encoder_fetch_stage(self._h, image, what, buf.ctypes.data, buf.nbytes)
+        if rc < 0:
+            raise Vp8lError(int(rc), "vp8l_encoder_fetch_stage")
+        return buf
+
+    def last_device_seconds(self):
+        return lib().vp8l_encoder_last_device_seconds(self._h)
+
+    def last_stage_seconds(self):
+        buf = (C.c_double * 8)()
+        k = lib().vp8l_encoder_last_stage_seconds(self._h, buf, 8)
+        return dict(zip(ENCODE_STAGES, buf[:k]))
+
+
+class Decoder:
+    """Batch decoder context (vp8l_decoder_*)."""
+
+    def __init__(self, device=-1):
+        self._h = C.c_void_p()
+        rc = lib().vp8l_decoder_create(device, C.byref(self._h))
+        if rc != OK:
+            raise Vp8lError(rc, "vp8l_decoder_create")
+
+    def close(self):
+        if self._h:
+            lib().vp8l_decoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    def decode_device(self, d_data_ptrs, lengths, widths, heights, d_argb_ptrs):
+        n = len(d_data_ptrs)
+        dp = (C.c_void_p * n)(*d_data_ptrs)
+        ln = (C.c_size_t * n)(*lengths)
+        ws = (C.c_uint32 * n)(*widths)
+        hs = (C.c_uint32 * n)(*heights)
+        op = (C.c_void_p * n)(*d_argb_ptrs)
+        status = (C.c_int * n)()
+        rc = lib().vp8l_decoder_decode_device(self._h, n, dp, ln, ws, hs, op, status)
+        if rc != OK:
+            raise Vp8lError(rc, "vp8l_decoder_decode_device")
+        return np.array(status[:], dtype=np.int32)
+
+    def last_device_seconds(self):
+        return lib().vp8l_decoder_last_device_seconds(self._h)
+
+
+def generate_device(mode, w, h, seed, ncolors, d_ptr, device=-1):
+    rc = lib().vp8l_generate_device(device, mode, w, h, seed, ncolors, d_ptr)
+    if rc != OK:
+        raise Vp8lError(rc, "vp8l_generate_device")

@@ -177,8 +177,10 @@ struct DecState {
   uint32_t *out;          // width*height pixels: the entropy decoder's target and the final image
   uint32_t *aux;          // tile images, palette, entropy image
   uint64_t aux_cap;
-  GroupTables *groups;    // storage for group tables
-  uint32_t group_cap;
+  GroupTables *groups;    // tables in use: `groups1` for sub-images and one-group images, else `groups_multi`
+  GroupTables *groups1;   // one table set (LDS on the device)
+  GroupTables *groups_multi;
+  uint32_t multi_cap;
   // bit reader
   uint64_t bytepos, buf;
   uint32_t cnt;
@@ -206,9 +208,9 @@ struct DecState {
 };
 
 VP8L_HD void dec_init(DecState &st, const uint8_t *data, uint64_t len, uint32_t *out, uint32_t *aux, uint64_t aux_cap,
-                      GroupTables *groups, uint32_t group_cap) {
+                      GroupTables *groups1, GroupTables *groups_multi, uint32_t multi_cap) {
   st.data = data; st.len = len; st.out = out; st.aux = aux; st.aux_cap = aux_cap;
-  st.groups = groups; st.group_cap = group_cap;
+  st.groups = groups1; st.groups1 = groups1; st.groups_multi = groups_multi; st.multi_cap = multi_cap;
   st.bytepos = 0; st.buf = 0; st.cnt = 0;
   st.w = st.h = st.nxf = st.seen = st.cix = st.main_cache_bits = 0;
   st.aux_used = 0;
@@ -455,7 +457,10 @@ VP8L_HD uint32_t dec_step(DecState &st) {
         break;
       }
       case kPhGroups: {  // vp8l.h:217-222
-        if (st.ngroups > st.group_cap) { st.need_groups = st.ngroups; VP8L_FAIL(kErrWorkspace); }
+        if (st.ngroups > 1) {
+          if (st.ngroups > st.multi_cap) { st.need_groups = st.ngroups; VP8L_FAIL(kErrWorkspace); }
+          st.groups = st.groups_multi;
+        }
         const uint32_t cb = st.main_cache_bits;
         for (uint32_t gi = 0; gi < st.ngroups; gi++) {
           const int rc = read_group(br, st.groups[gi], cb ? 1u << cb : 0u, st);
@@ -558,8 +563,8 @@ inline int host_decode(const uint8_t *data, size_t len, uint32_t *argb, size_t c
   DecState *st = new DecState;
   int status;
   for (;;) {
-    GroupTables *groups = new GroupTables[gcap];
-    dec_init(*st, data, len, argb, aux, aux_cap, groups, gcap);
+    GroupTables *groups = new GroupTables[gcap + 1];
+    dec_init(*st, data, len, argb, aux, aux_cap, groups, groups + 1, gcap);
     st->w = w; st->h = h;
     while (dec_step(*st) == kEvCopy)
       for (uint32_t i = 0; i < st->copy_len; i++) st->dst[st->copy_pos + i] = st->dst[st->copy_pos + i - st->copy_dist];

@@ -1,0 +1,344 @@
+// vp8l_decode.hip -- MI355X (gfx950) kernels of the VP8L decoder and the batch decoder context.
+//
+//   k_decode_entropy     stream grammar, Huffman tables, LZ77 / colour-cache pixel decode
+//                        (vp8l.h:83-328, huffman_io.h:74-219): one wave per image; lane 0 drives the
+//                        sequential state machine of vp8l_dec_core.h out of LDS, the whole wave
+//                        performs every back-reference copy.
+//   k_inverse_*          the inverse transforms in reverse order of appearance (vp8l.h:343-344,
+//                        transform.h:59-275): per-pixel parallel except the predictor, which runs
+//                        as a skewed wavefront (row y trails row y-1 by two pixels).
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <vector>
+
+#include "vp8l_amd.h"
+#include "vp8l_dec_core.h"
+#include "vp8l_host.h"
+#include "vp8l_kernels.h"
+
+namespace vp8l {
+
+struct DecImage {  // host-written
+  const uint8_t *data;
+  uint64_t len;
+  uint32_t w, h;
+  uint32_t *out;
+  uint32_t *aux;          // tile images / palette / entropy image
+  uint64_t aux_cap;
+  uint32_t *scratch;      // copy of the bundled indices for the colour-indexing inverse
+  GroupTables *groups;    // tables for streams with more than one Huffman group
+  uint32_t group_cap;
+  uint32_t pad;
+};
+
+struct DecResult {  // device-written
+  int32_t status;
+  uint32_t need_groups;
+  uint32_t nxf;
+  uint32_t pad;
+  XformRec xf[4];
+};
+
+__global__ __launch_bounds__(64) void k_decode_entropy(const DecImage *__restrict__ imgs, DecResult *__restrict__ res) {
+  __shared__ DecState st;
+  __shared__ GroupTables g0;
+  const uint32_t img = blockIdx.x, lane = threadIdx.x;
+  const DecImage im = imgs[img];
+  if (lane == 0) {
+    dec_init(st, im.data, im.len, im.out, im.aux, im.aux_cap, &g0, im.groups, im.group_cap);
+    st.w = im.w;
+    st.h = im.h;
+  }
+  __syncthreads();
+  for (;;) {
+    uint32_t ev = kEvDone;
+    if (lane == 0) ev = dec_step(st);
+    ev = (uint32_t)__shfl((int)ev, 0, 64);
+    if (ev != kEvCopy) break;
+    __syncthreads();  // lane 0's copy request (LDS) and pixel stores (HBM) before the wave's loads
+    __threadfence_block();
+    uint32_t *dst = st.dst;
+    const uint64_t pos = st.copy_pos;
+    const uint32_t dist = st.copy_dist, len = st.copy_len;
+    // pixel i of the copy equals pixel (i mod dist) of the source window: correct for overlapping
+    // references too, and every source is already final
+    for (uint32_t i = lane; i < len; i += 64) dst[pos + i] = dst[pos - dist + (dist >= len ? i : i % dist)];
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (lane == 0) {
+    DecResult &r = res[img];
+    r.status = st.status;
+    r.need_groups = st.need_groups;
+    r.nxf = st.nxf;
+    for (uint32_t k = 0; k < 4; k++) r.xf[k] = st.xf[k];
+  }
+}
+
+// Which transform this pass undoes for an image: pass k undoes the (k+1)-th from the end.
+__device__ __forceinline__ bool pass_transform(const DecResult &r, uint32_t pass, XformRec &x) {
+  if (r.status != 0 || pass >= r.nxf) return false;
+  x = r.xf[r.nxf - 1 - pass];
+  return true;
+}
+
+// Colour indexing expands bundled indices in place, so the indices are set aside first
+// (the reference copies the whole image, transform.h:62).
+__global__ __launch_bounds__(256) void k_inverse_stash(const DecImage *__restrict__ imgs, const DecResult *__restrict__ res,
+                                                       const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t pass) {
+  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb);
+  XformRec x;
+  if (!pass_transform(res[img], pass, x) || x.type != 3 || x.bits == 0) return;
+  const DecImage im = imgs[img];
+  const uint64_t cnt = (uint64_t)((im.w + (1u << x.bits) - 1) >> x.bits) * im.h;
+  const uint64_t p0 = (uint64_t)(unit - sb_first[img] * kUnitsPerSuper) * kUnit;
+  for (uint32_t k = 0; k < kUnit / 256; k++) {
+    const uint64_t p = p0 + k * 256 + threadIdx.x;
+    if (p < cnt) im.scratch[p] = im.out[p];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_inverse_pointwise(const DecImage *__restrict__ imgs, const DecResult *__restrict__ res,
+                                                           const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t pass) {
+  __shared__ uint32_t pal[kMaxPalette];
+  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  XformRec x;
+  if (!pass_transform(res[img], pass, x) || x.type == 0) return;
+  const DecImage im = imgs[img];
+  const uint64_t npx = (uint64_t)im.w * im.h;
+  const uint64_t p0 = (uint64_t)(unit - sb_first[img] * kUnitsPerSuper) * kUnit;
+  if (p0 >= npx) return;
+  const uint32_t *td = im.aux + x.data_off;
+  if (x.type == 2) {  // transform.h:94-103
+    for (uint32_t k = 0; k < kUnit / 256; k++) {
+      const uint64_t p = p0 + k * 256 + tid;
+      if (p < npx) im.out[p] = add_green(im.out[p]);
+    }
+  } else if (x.type == 1) {  // transform.h:196-218
+    for (uint32_t k = 0; k < kUnit / 256; k++) {
+      const uint64_t p = p0 + k * 256 + tid;
+      if (p >= npx) break;
+      const uint32_t y = (uint32_t)(p / im.w), xx = (uint32_t)(p - (uint64_t)y * im.w);
+      im.out[p] = inverse_cross_color(im.out[p], td[(y >> x.bits) * x.xsize + (xx >> x.bits)]);
+    }
+  } else {  // transform.h:59-87; only `width` pixels per row are produced (the reference overruns the row)
+    const uint32_t ncolors = x.xsize;
+    if (tid < ncolors) pal[tid] = td[tid];
+    __syncthreads();
+    const uint32_t bits = x.bits, per = 1u << bits, bpp = 8u >> bits, mask = (1u << bpp) - 1u;
+    const uint32_t cix = (im.w + per - 1) >> bits;
+    const uint32_t *idx = bits ? im.scratch : im.out;
+    for (uint32_t k = 0; k < kUnit / 256; k++) {
+      const uint64_t p = p0 + k * 256 + tid;
+      if (p >= npx) break;
+      const uint32_t y = (uint32_t)(p / im.w), xx = (uint32_t)(p - (uint64_t)y * im.w);
+      const uint32_t g = (idx[(uint64_t)y * cix + (xx >> bits)] >> 8) & 0xff;
+      const uint32_t c = (g >> ((xx & (per - 1)) * bpp)) & mask;
+      im.out[p] = c < ncolors ? pal[c] : 0u;  // the reference does not range-check the index (transform.h:82)
+    }
+  }
+}
+
+// Predictor inverse (transform.h:110-191).  Pixel (x,y) needs L, T, TL and TR = (x+1, y-1), so row y
+// may run two pixels behind row y-1: thread r of the block handles row y0+r and at step t the pixel
+// x = t - 2r.  One barrier per step; a band of `blockDim` rows at a time.
+__global__ __launch_bounds__(1024) void k_inverse_predictor(const DecImage *__restrict__ imgs, DecResult *__restrict__ res,
+                                                            uint32_t pass) {
+  const uint32_t img = blockIdx.x, r = threadIdx.x, R = blockDim.x;
+  XformRec xf;
+  if (!pass_transform(res[img], pass, xf) || xf.type != 0) return;
+  const DecImage im = imgs[img];
+  const uint32_t w = im.w, h = im.h;
+  const uint32_t *modes = im.aux + xf.data_off;
+  uint32_t *out = im.out;
+  bool bad = false;
+  for (uint32_t y0 = 0; y0 < h; y0 += R) {
+    const uint32_t y = y0 + r;
+    const bool live = y < h;
+    uint32_t *row = out + (uint64_t)y * w;
+    const uint32_t *up = row - w;
+    uint32_t L = 0, T = 0, TL = 0;
+    const uint32_t rows_here = h - y0 < R ? h - y0 : R;
+    const uint32_t steps = w + 2 * (rows_here - 1);
+    for (uint32_t t = 0; t < steps; t++) {
+      const int x = (int)t - 2 * (int)r;
+      if (live && x >= 0 && x < (int)w) {
+        uint32_t P;
+        if (y == 0) {
+          P = x == 0 ? 0xff000000u : L;
+        } else {
+          if (x == 0) { T = up[0]; P = T; }
+          else {
+            const uint32_t TR = (x == (int)w - 1) ? L : up[x + 1];  // transform.h:137
+            const uint32_t mode = (modes[(y >> xf.bits) * xf.xsize + ((uint32_t)x >> xf.bits)] >> 8) & 0xff;
+            if (mode > 13) bad = true;
+            P = predict(mode, L, T, TR, TL);
+            TL = T;
+            T = TR;
+          }
+          if (x == 0) { TL = T; T = w > 1 ? up[1] : 0u; }
+        }
+        L = px_add(row[x], P);
+        row[x] = L;
+      }
+      __syncthreads();
+    }
+  }
+  if (bad) atomicExch(&res[img].status, (int32_t)kErrInvalidVp8l);
+}
+
+}  // namespace vp8l
+
+// =============================================================================================
+// Host side: batch decoder context
+// =============================================================================================
+using namespace vp8l;
+
+struct vp8l_decoder {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::mutex mu;
+  DeviceBuffer d_imgs, d_res, d_sbfirst, d_aux, d_scratch, d_groups;
+  double last_seconds = 0;
+};
+
+extern "C" int vp8l_decoder_create(int device, vp8l_decoder **out) {
+  if (!out) return VP8L_ERR_BAD_ARGUMENT;
+  int rc = select_device(device, &device);
+  if (rc != VP8L_OK) return rc;
+  vp8l_decoder *d = new (std::nothrow) vp8l_decoder;
+  if (!d) return VP8L_ERR_NO_MEMORY;
+  d->device = device;
+  if (!hip_ok(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking), "hipStreamCreate") ||
+      !hip_ok(hipEventCreate(&d->ev0), "hipEventCreate") || !hip_ok(hipEventCreate(&d->ev1), "hipEventCreate")) {
+    vp8l_decoder_destroy(d);
+    return VP8L_ERR_HIP;
+  }
+  *out = d;
+  return VP8L_OK;
+}
+
+extern "C" void vp8l_decoder_destroy(vp8l_decoder *d) {
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
+  if (d->ev0) (void)hipEventDestroy(d->ev0);
+  if (d->ev1) (void)hipEventDestroy(d->ev1);
+  DeviceBuffer *bufs[] = {&d->d_imgs, &d->d_res, &d->d_sbfirst, &d->d_aux, &d->d_scratch, &d->d_groups};
+  for (auto *b : bufs) b->release();
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+}
+
+namespace {
+
+// One pass over the images listed in `idx` with `group_cap` multi-group table sets per image.
+int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t *const *d_data, const size_t *len,
+                const uint32_t *width, const uint32_t *height, uint32_t *const *d_argb, uint32_t group_cap,
+                std::vector<DecResult> &results) {
+  const uint32_t m = (uint32_t)idx.size();
+  std::vector<DecImage> imgs(m);
+  std::vector<uint32_t> sb_first(m + 1, 0);
+  uint64_t aux_total = 0, scratch_total = 0, sb_total = 0;
+  for (uint32_t k = 0; k < m; k++) {
+    const uint32_t i = idx[k], w = width[i], h = height[i];
+    DecImage &im = imgs[k];
+    im.data = d_data[i];
+    im.len = len[i];
+    im.w = w;
+    im.h = h;
+    im.out = d_argb[i];
+    im.aux_cap = 3ull * ((w + 3) / 4) * ((h + 3) / 4) + 256;
+    im.aux = reinterpret_cast<uint32_t *>(aux_total);       // offsets for now, bases added below
+    im.scratch = reinterpret_cast<uint32_t *>(scratch_total);
+    im.group_cap = group_cap;
+    aux_total += (im.aux_cap + 63) & ~63ull;
+    scratch_total += ((uint64_t)((w + 1) / 2) * h + 63) & ~63ull;
+    sb_first[k] = (uint32_t)sb_total;
+    sb_total += ((uint64_t)w * h + kSuper - 1) / kSuper;
+    if (sb_total > 0x3fffffffu) return VP8L_ERR_NO_MEMORY;
+  }
+  sb_first[m] = (uint32_t)sb_total;
+  const bool ok = d->d_imgs.reserve(m * sizeof(DecImage)) && d->d_res.reserve(m * sizeof(DecResult)) &&
+                  d->d_sbfirst.reserve((m + 1) * 4) && d->d_aux.reserve(aux_total * 4) &&
+                  d->d_scratch.reserve(scratch_total * 4) &&
+                  d->d_groups.reserve((size_t)m * group_cap * sizeof(GroupTables) + 16);
+  if (!ok) return VP8L_ERR_NO_MEMORY;
+  for (uint32_t k = 0; k < m; k++) {
+    imgs[k].aux = d->d_aux.as<uint32_t>() + reinterpret_cast<uintptr_t>(imgs[k].aux);
+    imgs[k].scratch = d->d_scratch.as<uint32_t>() + reinterpret_cast<uintptr_t>(imgs[k].scratch);
+    imgs[k].groups = d->d_groups.as<GroupTables>() + (size_t)k * group_cap;
+  }
+  hipStream_t s = d->stream;
+  auto *dimgs = d->d_imgs.as<DecImage>();
+  auto *dres = d->d_res.as<DecResult>();
+  auto *sbf = d->d_sbfirst.as<uint32_t>();
+  if (!hip_ok(hipMemcpyAsync(dimgs, imgs.data(), m * sizeof(DecImage), hipMemcpyHostToDevice, s), "upload images") ||
+      !hip_ok(hipMemcpyAsync(sbf, sb_first.data(), (m + 1) * 4, hipMemcpyHostToDevice, s), "upload table") ||
+      !hip_ok(hipMemsetAsync(dres, 0, m * sizeof(DecResult), s), "clear results"))
+    return VP8L_ERR_HIP;
+  const uint32_t gunits = (uint32_t)(sb_total * kUnitsPerSuper);
+  (void)hipEventRecord(d->ev0, s);
+  hipLaunchKernelGGL(k_decode_entropy, dim3(m), dim3(64), 0, s, dimgs, dres);
+  for (uint32_t pass = 0; pass < 4; pass++) {
+    hipLaunchKernelGGL(k_inverse_stash, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m, pass);
+    hipLaunchKernelGGL(k_inverse_pointwise, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m, pass);
+    hipLaunchKernelGGL(k_inverse_predictor, dim3(m), dim3(1024), 0, s, dimgs, dres, pass);
+  }
+  (void)hipEventRecord(d->ev1, s);
+  if (!hip_ok(hipGetLastError(), "kernel launch")) return VP8L_ERR_HIP;
+  results.resize(m);
+  if (!hip_ok(hipMemcpyAsync(results.data(), dres, m * sizeof(DecResult), hipMemcpyDeviceToHost, s), "download results") ||
+      !hip_ok(hipStreamSynchronize(s), "decode batch"))
+    return VP8L_ERR_HIP;
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, d->ev0, d->ev1);
+  d->last_seconds += ms * 1e-3;
+  return VP8L_OK;
+}
+
+}  // namespace
+
+extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8_t *const *d_data, const size_t *len,
+                                          const uint32_t *width, const uint32_t *height, uint32_t *const *d_argb, int *status) {
+  if (!d || !d_data || !len || !width || !height || !d_argb || !status) return VP8L_ERR_BAD_ARGUMENT;
+  if (n == 0) return VP8L_OK;
+  if (n > 0x7fffffffu) return VP8L_ERR_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lock(d->mu);
+  if (!hip_ok(hipSetDevice(d->device), "hipSetDevice")) return VP8L_ERR_HIP;
+  d->last_seconds = 0;
+  std::vector<uint32_t> pending;
+  for (size_t i = 0; i < n; i++) {
+    status[i] = VP8L_OK;
+    if (!d_data[i] || !d_argb[i] || width[i] == 0 || height[i] == 0 || width[i] > kMaxDim || height[i] > kMaxDim ||
+        ((uintptr_t)d_data[i] & 3)) {
+      status[i] = VP8L_ERR_BAD_ARGUMENT;
+      continue;
+    }
+    pending.push_back((uint32_t)i);
+  }
+  uint32_t group_cap = 4;
+  while (!pending.empty()) {
+    std::vector<DecResult> results;
+    const int rc = decode_pass(d, pending, d_data, len, width, height, d_argb, group_cap, results);
+    if (rc != VP8L_OK) return rc;
+    std::vector<uint32_t> again;
+    uint32_t need = 0;
+    for (size_t k = 0; k < pending.size(); k++) {
+      const DecResult &r = results[k];
+      if (r.status == kErrWorkspace && r.need_groups > group_cap) {
+        again.push_back(pending[k]);  // a stream with more Huffman groups than this pass provided
+        need = std::max(need, r.need_groups);
+      } else {
+        status[pending[k]] = r.status;
+      }
+    }
+    pending.swap(again);
+    group_cap = need;
+  }
+  return VP8L_OK;
+}
+
+extern "C" double vp8l_decoder_last_device_seconds(const vp8l_decoder *d) { return d ? d->last_seconds : 0.0; }

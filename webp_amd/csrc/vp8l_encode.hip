@@ -1,0 +1,956 @@
+// vp8l_encode.hip -- MI355X (gfx950) kernels of the VP8L encoder and the batch encoder context.
+//
+// Pipeline for a batch of independent images, everything resident in HBM, no host round trip
+// between stages:
+//   k_palette_scan / k_palette_finalize   CreatePallete            vp8l.h:372-380
+//   k_transform                           subtract green / colour indexing + bundling
+//                                                                  vp8l.h:411-459, transform.cpp:88-106
+//   k_lz77                                LZ77<uint32_t>::pack best match at every position
+//                                                                  lz77.h:51-72
+//   k_parse_exits / k_parse_chain / k_parse_mark   the greedy parse (which positions start a token)
+//                                                                  lz77.h:33-92
+//   k_histogram                           the five symbol histograms          vp8l.h:516-535
+//   k_entropy_header                      Huffman codes + everything in front of the tokens
+//                                                                  vp8l.h:460-467,536-540; huffman_io.h:331-410
+//   k_bitcount / k_scan / k_emit          token bits              vp8l.h:545-583, bit_writer.h:45-64
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "vp8l_amd.h"
+#include "vp8l_enc_core.h"
+#include "vp8l_host.h"
+#include "vp8l_kernels.h"
+
+namespace vp8l {
+
+// =============================================================================================
+// Palette detection.  The reference inserts every pixel into a std::set and gives up as soon as
+// the set holds more than 256 colours.  Here every block keeps an exact hash set of the colours
+// of its 16384 pixels in LDS, gives up (for the whole image) once it has seen more than 256, and
+// otherwise merges into the image's set in HBM.
+// =============================================================================================
+constexpr uint32_t kSetSlots = 1024;
+constexpr uint64_t kEmptySlot = ~0ull;
+
+__device__ __forceinline__ uint32_t hash_px(uint32_t v) { return (v * 0x9E3779B1u) >> 22; }
+
+// Returns 1 if newly inserted, 0 if already present, 2 if the table is full.
+template <class Slot>
+__device__ __forceinline__ int set_insert(Slot *set, uint32_t v) {
+  uint32_t h = hash_px(v);
+  for (uint32_t probe = 0; probe < kSetSlots; probe++) {
+    const unsigned long long old = atomicCAS((unsigned long long *)&set[h], (unsigned long long)kEmptySlot, (unsigned long long)v);
+    if (old == kEmptySlot) return 1;
+    if ((uint32_t)old == v) return 0;
+    h = (h + 1) & (kSetSlots - 1);
+  }
+  return 2;
+}
+
+__global__ __launch_bounds__(256) void k_palette_scan(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
+                                                      const uint32_t *__restrict__ sb_first, uint32_t n,
+                                                      unsigned long long *__restrict__ gsets) {
+  __shared__ unsigned long long set[kSetSlots];
+  __shared__ uint32_t s_count, s_over;
+  const uint32_t sb = blockIdx.x, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  const EncImage im = imgs[img];
+  const uint64_t npx = (uint64_t)im.w * im.h;
+  const uint64_t base = (uint64_t)(sb - sb_first[img]) * kSuper;
+  if (base >= npx) return;
+  if (__hip_atomic_load(&st[img].pal_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  for (uint32_t i = tid; i < kSetSlots; i += 256) set[i] = kEmptySlot;
+  if (tid == 0) { s_count = 0; s_over = 0; }
+  __syncthreads();
+  for (uint32_t it = 0; it < kSuper / 256; it++) {
+    const uint64_t i = base + (uint64_t)it * 256 + tid;
+    if (i < npx) {
+      const int r = set_insert(set, im.argb[i]);
+      if (r == 1) atomicAdd(&s_count, 1u);
+      if (r == 2) s_over = 1;
+    }
+    if (tid == 0 && (it & 7) == 7 &&
+        __hip_atomic_load(&st[img].pal_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      s_over = 1;
+    __syncthreads();
+    const bool too_many = s_count > kMaxPalette;
+    const bool stop = too_many || s_over;
+    __syncthreads();
+    if (stop) {
+      if (tid == 0 && too_many) __hip_atomic_store(&st[img].pal_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (base + (uint64_t)(it + 1) * 256 >= npx) break;
+  }
+  unsigned long long *gset = gsets + (size_t)img * kSetSlots;
+  for (uint32_t s = tid; s < kSetSlots; s += 256) {
+    const unsigned long long e = set[s];
+    if (e == kEmptySlot) continue;
+    if (__hip_atomic_load(&st[img].pal_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    const int r = set_insert(gset, (uint32_t)e);
+    if (r == 2 || (r == 1 && atomicAdd(&st[img].pal_count, 1u) + 1 > kMaxPalette))
+      __hip_atomic_store(&st[img].pal_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_palette_finalize(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
+                                                          const unsigned long long *__restrict__ gsets) {
+  __shared__ uint32_t list[kSetSlots];
+  __shared__ uint32_t s_k;
+  const uint32_t img = blockIdx.x, tid = threadIdx.x;
+  const EncImage im = imgs[img];
+  EncState &s = st[img];
+  if (tid == 0) s_k = 0;
+  __syncthreads();
+  const bool none = s.pal_overflow || s.pal_count > kMaxPalette || s.pal_count == 0;
+  if (none) {
+    if (tid == 0) { s.ncolors = 0; s.bits = 0; s.xsize = im.w; s.M = im.w * im.h; }
+    return;
+  }
+  const unsigned long long *gset = gsets + (size_t)img * kSetSlots;
+  for (uint32_t i = tid; i < kSetSlots; i += 256) {
+    const unsigned long long e = gset[i];
+    if (e != kEmptySlot) list[atomicAdd(&s_k, 1u)] = (uint32_t)e;
+  }
+  __syncthreads();
+  const uint32_t k = s_k;
+  if (tid < k) {  // ascending order, as iterating the reference's std::set gives (vp8l.h:604-605)
+    const uint32_t v = list[tid];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < k; j++) rank += list[j] < v;
+    s.palette[rank] = v;
+  }
+  if (tid == 0) {
+    const uint32_t bits = palette_bits(k);
+    s.ncolors = k;
+    s.bits = bits;
+    s.xsize = (im.w + (1u << bits) - 1) >> bits;
+    s.M = s.xsize * im.h;
+  }
+}
+
+// =============================================================================================
+// Forward transform: one coded pixel per thread-iteration, 8 B of HBM traffic per pixel on the
+// subtract-green path, 4 + 4/2^bits on the colour-indexing path.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_transform(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                   const uint32_t *__restrict__ sb_first, uint32_t n,
+                                                   uint32_t *__restrict__ pix) {
+  __shared__ uint32_t pal[kMaxPalette];
+  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  const EncImage im = imgs[img];
+  const uint32_t M = st[img].M, ncolors = st[img].ncolors;
+  const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
+  if (p0 >= M) return;
+  uint32_t *dst = pix + im.pos0;
+  if (ncolors == 0) {
+#pragma unroll 4
+    for (uint32_t k = 0; k < kUnit / 256; k++) {
+      const uint32_t p = p0 + k * 256 + tid;
+      if (p < M) dst[p] = subtract_green(im.argb[p]);
+    }
+    return;
+  }
+  if (tid < ncolors) pal[tid] = st[img].palette[tid];
+  __syncthreads();
+  const uint32_t bits = st[img].bits, xsize = st[img].xsize, depth = 8u >> bits, per = 1u << bits;
+  for (uint32_t k = 0; k < kUnit / 256; k++) {
+    const uint32_t p = p0 + k * 256 + tid;
+    if (p >= M) break;
+    const uint32_t y = p / xsize, xp = p - y * xsize;
+    uint32_t code = 0xff000000u;
+    for (uint32_t j = 0; j < per; j++) {
+      const uint32_t x = (xp << bits) + j;
+      if (x >= im.w) break;
+      const uint32_t v = im.argb[(uint64_t)y * im.w + x];
+      uint32_t lo = 0, hi = ncolors;  // index of v in the sorted palette = the first equal entry (vp8l.h:438-443)
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pal[mid] < v) lo = mid + 1; else hi = mid; }
+      code |= lo << (8 + depth * j);
+    }
+    dst[p] = code;
+  }
+}
+
+// =============================================================================================
+// LZ77 best match at EVERY position (lz77.h:51-72): over distances d = 1..min(p,1024),
+// len(d) = min(run of data[q-d]==data[q] from q=p, d, 128, M-p); the longest wins, the largest d
+// among equals.  The parse later picks the positions it actually visits.
+//
+// Formulation: for a fixed distance the equality run length at p is known from the run at p+1,
+// so positions are scanned BACKWARDS and every distance keeps one register: the first position
+// >= p where data[q-d] != data[q].  One wave owns a tile of kLzTile positions; lane l owns the
+// 16 distances 16l+1..16l+16, which at position p need the 16 consecutive pixels
+// data[p-16l-16 .. p-16l-1]: a window that slides by one pixel per step, held in registers and
+// refilled with one 64-byte load per 16 steps.  Cost is 1024 cell updates per position
+// whatever the image content.  Positions are handled in aligned chunks of 16 and coordinates are
+// kept relative to the chunk (pos - P + 16, P = last position of the chunk) so every per-step
+// constant is a small literal.
+// =============================================================================================
+template <bool HEAD>
+__device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uint32_t *__restrict__ match, const uint32_t M,
+                                          const uint32_t a, const uint32_t b, const int lane) {
+  const uint32_t qs = (b + 127 < M - 1) ? b + 127 : M - 1;
+  int ctop = (int)(qs >> 4);
+  const int cbot = (int)(a >> 4);
+  int P = ctop * 16 + 15;
+  uint32_t mis[16];  // per distance: first mismatch position at or after the current one (chunk relative)
+  {
+    const uint32_t lim = ((uint32_t)P + 1 < M ? (uint32_t)P + 1 : M) - (uint32_t)P + 16;
+#pragma unroll
+    for (int j = 0; j < 16; j++) mis[j] = lim;
+  }
+  uint32_t cap[31];  // cap[j - s + 15] = (position + distance) in chunk coordinates: a match cannot overlap its source
+#pragma unroll
+  for (int k = 0; k < 31; k++) cap[k] = 16u * (uint32_t)lane + 2u + (uint32_t)k;
+  uint32_t win[31];  // win[k] = data[P - 16*lane - 1 - k]
+  {
+    const int a1 = P - 16 * lane - 15;  // 16 aligned pixels, the last one (distance 0) unused
+    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
+    if (!HEAD || a1 >= 0) {
+      const uint4 *src = reinterpret_cast<const uint4 *>(data + a1);
+      v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3];
+    }
+    const uint32_t L[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+    for (int i = 0; i < 15; i++) win[14 - i] = L[i];
+  }
+  for (int ck = ctop; ck >= cbot; ck--, P -= 16) {
+    {
+      const int a0 = P - 16 * lane - 31;
+      uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
+      if (!HEAD || a0 >= 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(data + a0);
+        v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3];
+      }
+      const uint32_t L[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+      for (int i = 0; i < 16; i++) win[30 - i] = L[i];
+    }
+    uint32_t X[16];  // the 16 pixels of this chunk, the same in every lane
+    {
+      const uint4 *src = reinterpret_cast<const uint4 *>(data + (P - 15));
+      const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+      const uint32_t L[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+      for (int i = 0; i < 16; i++) X[15 - i] = L[i];
+    }
+    uint32_t res = 0;
+    const bool writes = (uint32_t)(P - 15) < b;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const uint32_t p = (uint32_t)(P - s);
+      if (p >= M) continue;  // past the end of the image (last chunk only)
+      const uint32_t x = X[s];
+      const uint32_t here = 16u - (uint32_t)s;
+#pragma unroll
+      for (int j = 0; j < 16; j++) mis[j] = (win[s + j] == x) ? mis[j] : here;
+      if (HEAD) {  // distances that reach before the first pixel never match
+#pragma unroll
+        for (int j = 0; j < 16; j++) mis[j] = ((uint32_t)(16 * lane + j + 1) > p) ? here : mis[j];
+      }
+      if (p < b) {
+        const uint32_t lim = here + kMaxLen;  // at most 128 pixels
+        uint32_t key = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          uint32_t t = mis[j] < cap[j - s + 15] ? mis[j] : cap[j - s + 15];
+          t = t < lim ? t : lim;
+          const uint32_t kj = (t << 4) | (uint32_t)j;
+          key = key > kj ? key : kj;
+        }
+        // (end of match, distance-1): the largest distance wins among equal lengths (lz77.h:68)
+        uint32_t K = ((key & ~15u) << 6) | ((uint32_t)lane << 4) | (key & 15u);
+        K = wave_max_u32(K);
+        uint32_t len = (K >> 10) - here;
+        const uint32_t dist = (K & 1023u) + 1u;
+        if (p == M - 1) len = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
+        if (lane == s) res = len ? (len | (dist << 8)) : 0u;
+      }
+    }
+    if (writes && lane < 16) {
+      const uint32_t p = (uint32_t)(P - lane);
+      if (p < b && p < M) match[p] = res;
+    }
+#pragma unroll
+    for (int k = 0; k < 15; k++) win[k] = win[k + 16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) mis[j] += 16;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                              const uint32_t *__restrict__ sb_first, uint32_t n,
+                                              const uint32_t *__restrict__ pix, uint32_t *__restrict__ match) {
+  constexpr uint32_t kPerSuper = kSuper / kLzBlock;
+  const uint32_t blk = blockIdx.x, sb = blk / kPerSuper, img = find_image(sb_first, n, sb);
+  const uint32_t M = st[img].M;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t a = (blk - sb_first[img] * kPerSuper) * kLzBlock + (uint32_t)wave * kLzTile;
+  if (a >= M) return;
+  const uint32_t b = a + kLzTile < M ? a + kLzTile : M;
+  const uint64_t pos0 = imgs[img].pos0;
+  if (a == 0) lz77_tile<true>(pix + pos0, match + pos0, M, a, b, lane);
+  else lz77_tile<false>(pix + pos0, match + pos0, M, a, b, lane);
+}
+
+// =============================================================================================
+// Greedy parse.  adv[p] = max(1, len[p]); the token starts are p0 = 0, p_{k+1} = p_k + adv[p_k].
+// A jump is at most 128 long, so the chain enters every 128-position block through one of its
+// 128 positions.  (1) per block, exit[p] = where the chain that passes through p first lands in
+// the next block; (2) per superblock of 128 blocks, the exit for each of the 128 possible
+// entries; (3) per image, a short serial walk over superblocks; (4) per superblock, entries of
+// its blocks, then every block marks its token starts.  All out of LDS.
+// =============================================================================================
+constexpr uint32_t kRowPad = kBlockLen + 4;  // LDS row stride: spreads the 128 block rows over the banks
+
+__device__ __forceinline__ void load_advances(const uint32_t *__restrict__ match, uint32_t M, uint32_t p0, uint8_t *adv, uint32_t tid) {
+  for (uint32_t i = tid * 4; i < kSuper; i += 128 * 4) {
+    uint32_t packed = 0x01010101u;
+    if (p0 + i + 3 < M) {
+      const uint4 m = *reinterpret_cast<const uint4 *>(match + p0 + i);
+      const uint32_t l0 = m.x & 0xff, l1 = m.y & 0xff, l2 = m.z & 0xff, l3 = m.w & 0xff;
+      packed = (l0 ? l0 : 1u) | ((l1 ? l1 : 1u) << 8) | ((l2 ? l2 : 1u) << 16) | ((l3 ? l3 : 1u) << 24);
+    } else {
+      for (uint32_t k = 0; k < 4; k++)
+        if (p0 + i + k < M) {
+          const uint32_t l = match[p0 + i + k] & 0xff;
+          packed = (packed & ~(0xffu << (8 * k))) | ((l ? l : 1u) << (8 * k));
+        }
+    }
+    const uint32_t row = i / kBlockLen, col = i % kBlockLen;
+    *reinterpret_cast<uint32_t *>(adv + row * kRowPad + col) = packed;
+  }
+}
+
+// exit[p] for all p of block `row` (thread per block, backwards)
+__device__ __forceinline__ void block_exits(const uint8_t *adv, uint8_t *ex, uint32_t row) {
+  const uint8_t *a = adv + row * kRowPad;
+  uint8_t *e = ex + row * kRowPad;
+  for (int i = (int)kBlockLen - 1; i >= 0; i--) {
+    const uint32_t q = (uint32_t)i + a[i];
+    e[i] = (uint8_t)(q >= kBlockLen ? q - kBlockLen : e[q]);
+  }
+}
+
+__global__ __launch_bounds__(128) void k_parse_exits(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                     const uint32_t *__restrict__ sb_first, uint32_t n,
+                                                     const uint32_t *__restrict__ match, uint8_t *__restrict__ sx) {
+  __shared__ __attribute__((aligned(16))) uint8_t adv[kBlocksPerSuper * kRowPad];
+  __shared__ __attribute__((aligned(16))) uint8_t ex[kBlocksPerSuper * kRowPad];
+  const uint32_t sb = blockIdx.x, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  const uint32_t M = st[img].M;
+  const uint32_t p0 = (sb - sb_first[img]) * kSuper;
+  if (p0 >= M) return;
+  load_advances(match + imgs[img].pos0, M, p0, adv, tid);
+  __syncthreads();
+  block_exits(adv, ex, tid);
+  __syncthreads();
+  uint32_t e = tid;
+  for (uint32_t r = 0; r < kBlocksPerSuper; r++) e = ex[r * kRowPad + e];
+  sx[(size_t)sb * kBlockLen + tid] = (uint8_t)e;
+}
+
+__global__ __launch_bounds__(256) void k_parse_chain(const EncState *__restrict__ st, const uint32_t *__restrict__ sb_first,
+                                                     const uint8_t *__restrict__ sx, uint8_t *__restrict__ entry) {
+  __shared__ __attribute__((aligned(16))) uint8_t tab[128 * kBlockLen];
+  const uint32_t img = blockIdx.x, tid = threadIdx.x;
+  const uint32_t nsb = (st[img].M + kSuper - 1) / kSuper, sb0 = sb_first[img];
+  uint32_t e = 0;
+  for (uint32_t g = 0; g < nsb; g += 128) {
+    const uint32_t cnt = nsb - g < 128 ? nsb - g : 128;
+    const uint4 *src = reinterpret_cast<const uint4 *>(sx + (size_t)(sb0 + g) * kBlockLen);
+    for (uint32_t i = tid; i < cnt * kBlockLen / 16; i += 256) reinterpret_cast<uint4 *>(tab)[i] = src[i];
+    __syncthreads();
+    if (tid == 0)
+      for (uint32_t i = 0; i < cnt; i++) { entry[sb0 + g + i] = (uint8_t)e; e = tab[i * kBlockLen + e]; }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(128) void k_parse_mark(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                    const uint32_t *__restrict__ sb_first, uint32_t n,
+                                                    const uint32_t *__restrict__ match, const uint8_t *__restrict__ entry,
+                                                    uint32_t *__restrict__ flags) {
+  __shared__ __attribute__((aligned(16))) uint8_t adv[kBlocksPerSuper * kRowPad];
+  __shared__ __attribute__((aligned(16))) uint8_t ex[kBlocksPerSuper * kRowPad];
+  __shared__ uint8_t ent[kBlocksPerSuper];
+  const uint32_t sb = blockIdx.x, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  const uint32_t M = st[img].M;
+  const uint32_t p0 = (sb - sb_first[img]) * kSuper;
+  if (p0 >= M) return;
+  load_advances(match + imgs[img].pos0, M, p0, adv, tid);
+  __syncthreads();
+  block_exits(adv, ex, tid);
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t e = entry[sb];
+    for (uint32_t r = 0; r < kBlocksPerSuper; r++) { ent[r] = (uint8_t)e; e = ex[r * kRowPad + e]; }
+  }
+  __syncthreads();
+  unsigned long long lo = 0, hi = 0;  // token starts of this thread's block
+  const uint32_t bstart = p0 + tid * kBlockLen;
+  for (uint32_t q = ent[tid]; q < kBlockLen && bstart + q < M; q += adv[tid * kRowPad + q]) {
+    if (q < 64) lo |= 1ull << q; else hi |= 1ull << (q - 64);
+  }
+  uint4 out;
+  out.x = (uint32_t)lo; out.y = (uint32_t)(lo >> 32); out.z = (uint32_t)hi; out.w = (uint32_t)(hi >> 32);
+  *reinterpret_cast<uint4 *>(flags + (imgs[img].pos0 + bstart) / 32) = out;
+}
+
+__device__ __forceinline__ uint32_t flag_at(const uint32_t *__restrict__ flags, uint64_t gpos) {
+  return (flags[gpos >> 5] >> (gpos & 31)) & 1u;
+}
+
+// =============================================================================================
+// Histograms (vp8l.h:516-535): LDS-private per block, merged into the image's 5x280 counters.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_histogram(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                   const uint32_t *__restrict__ sb_first, uint32_t n,
+                                                   const uint32_t *__restrict__ pix, const uint32_t *__restrict__ match,
+                                                   const uint32_t *__restrict__ flags, uint32_t *__restrict__ histo) {
+  __shared__ uint32_t h[kNumCodes * kCodeStride];
+  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  const uint32_t M = st[img].M, xsize = st[img].xsize;
+  const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
+  if (p0 >= M) return;
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) h[i] = 0;
+  __syncthreads();
+  const uint64_t pos0 = imgs[img].pos0;
+  for (uint32_t k = 0; k < kUnit / 256; k++) {
+    const uint32_t p = p0 + k * 256 + tid;
+    if (p >= M || !flag_at(flags, pos0 + p)) continue;
+    const uint32_t m = match[pos0 + p], len = m & 0xff;
+    if (len == 0) {
+      const uint32_t px = pix[pos0 + p];
+      atomicAdd(&h[kGreen * kCodeStride + ((px >> 8) & 0xff)], 1u);
+      atomicAdd(&h[kRed * kCodeStride + ((px >> 16) & 0xff)], 1u);
+      atomicAdd(&h[kBlue * kCodeStride + (px & 0xff)], 1u);
+      atomicAdd(&h[kAlpha * kCodeStride + (px >> 24)], 1u);
+    } else {
+      uint32_t sym, nb, eb;
+      prefix_encode(len, sym, nb, eb);
+      atomicAdd(&h[kGreen * kCodeStride + 256 + sym], 1u);
+      prefix_encode(dist_to_code(xsize, (m >> 8) & 0x7ff), sym, nb, eb);
+      atomicAdd(&h[kDist * kCodeStride + sym], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t *g = histo + (size_t)img * kNumCodes * kCodeStride;
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256)
+    if (h[i]) atomicAdd(&g[i], h[i]);
+}
+
+// =============================================================================================
+// Per image: the five Huffman codes and every bit in front of the first token.  A few hundred
+// symbols of strictly sequential work (sorted-merge Huffman with the reference's tie rule, RLE,
+// nested code): lane 0 of one wave runs the host/device core out of LDS.
+// =============================================================================================
+struct HeaderShared {
+  SubImageScratch sub;
+  CodeTables tables;
+  uint32_t histo[kNumCodes * kCodeStride];
+  uint32_t palette[kMaxPalette];
+};
+
+__global__ __launch_bounds__(64) void k_entropy_header(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
+                                                       const uint32_t *__restrict__ histo, CodeTables *__restrict__ tables,
+                                                       uint8_t *__restrict__ out) {
+  __shared__ HeaderShared sh;
+  const uint32_t img = blockIdx.x, tid = threadIdx.x;
+  const EncImage im = imgs[img];
+  const uint32_t *g = histo + (size_t)img * kNumCodes * kCodeStride;
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 64) sh.histo[i] = g[i];
+  for (uint32_t i = tid; i < kMaxPalette; i += 64) sh.palette[i] = st[img].palette[i];
+  __syncthreads();
+  if (tid == 0) {
+    BitSink bw;
+    bw.init(reinterpret_cast<uint32_t *>(out + im.out_off));
+    int rc = write_stream_prefix(bw, im.w, im.h, sh.palette, st[img].ncolors, sh.sub);
+    if (rc == 0) rc = build_and_write_codes(bw, sh.histo, sh.tables, sh.sub.desc);
+    bw.flush();
+    st[img].hdr_bits = (uint32_t)bw.bits();
+    st[img].status = rc;
+  }
+  __syncthreads();
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(&sh.tables);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(&tables[img]);
+  for (uint32_t i = tid; i < sizeof(CodeTables) / 4; i += 64) dst[i] = src[i];
+}
+
+// =============================================================================================
+// Token bits: count per unit, scan per image, emit through an LDS staging window.
+// =============================================================================================
+struct CountPut {
+  uint32_t bits = 0;
+  __device__ __forceinline__ void operator()(uint32_t, uint32_t n) { bits += n; }
+};
+
+__device__ __forceinline__ void load_tables(CodeTables &dst, const CodeTables *__restrict__ src, uint32_t tid) {
+  const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
+  uint32_t *d = reinterpret_cast<uint32_t *>(&dst);
+  for (uint32_t i = tid; i < sizeof(CodeTables) / 4; i += 256) d[i] = s[i];
+}
+
+__global__ __launch_bounds__(256) void k_bitcount(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                  const uint32_t *__restrict__ sb_first, uint32_t n,
+                                                  const uint32_t *__restrict__ pix, const uint32_t *__restrict__ match,
+                                                  const uint32_t *__restrict__ flags, const CodeTables *__restrict__ tables,
+                                                  uint32_t *__restrict__ unit_bits) {
+  __shared__ CodeTables tab;
+  __shared__ uint32_t wsum[4];
+  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  const uint32_t M = st[img].M, xsize = st[img].xsize;
+  const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
+  if (p0 >= M) return;
+  load_tables(tab, &tables[img], tid);
+  __syncthreads();
+  const uint64_t pos0 = imgs[img].pos0;
+  CountPut cnt;
+  for (uint32_t k = 0; k < kUnit / 256; k++) {
+    const uint32_t p = p0 + k * 256 + tid;
+    if (p >= M || !flag_at(flags, pos0 + p)) continue;
+    const uint32_t m = match[pos0 + p], len = m & 0xff;
+    emit_token(cnt, tab, len ? 0u : pix[pos0 + p], len, (m >> 8) & 0x7ff, xsize);
+  }
+  const uint32_t s = wave_sum_u32(cnt.bits);
+  if ((tid & 63) == 0) wsum[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) unit_bits[unit] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Exclusive scan of the unit bit counts of one image (starting at the header length).  Also clears
+// the stream word in which each unit starts: k_emit ORs into those shared words and plainly stores
+// all others, so no bulk clear of the output buffer is needed.
+__global__ __launch_bounds__(256) void k_scan(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
+                                              const uint32_t *__restrict__ sb_first, const uint32_t *__restrict__ unit_bits,
+                                              uint64_t *__restrict__ unit_off, uint8_t *__restrict__ out) {
+  __shared__ uint32_t wsum[4];
+  const uint32_t img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const EncImage im = imgs[img];
+  EncState &s = st[img];
+  if (s.status != 0) return;
+  const uint32_t nunits = (s.M + kUnit - 1) / kUnit, unit0 = sb_first[img] * kUnitsPerSuper;
+  uint32_t *out32 = reinterpret_cast<uint32_t *>(out + im.out_off);
+  const uint64_t hdr_word = s.hdr_bits >> 5;
+  uint64_t running = s.hdr_bits;
+  for (uint32_t base = 0; base < nunits; base += 256) {
+    const uint32_t u = base + tid;
+    const uint32_t v = u < nunits ? unit_bits[unit0 + u] : 0u;
+    const uint32_t incl = wave_incl_scan_u32(v, (int)lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint64_t before = running;
+    for (uint32_t k = 0; k < wave; k++) before += wsum[k];
+    const uint64_t total = (uint64_t)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (u < nunits) {
+      const uint64_t off = before + incl - v;
+      unit_off[unit0 + u] = off;
+      if (u > 0 && (off >> 5) > hdr_word) out32[off >> 5] = 0;
+    }
+    running += total;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    s.total_bits = running;
+    if ((running >> 5) > hdr_word) out32[running >> 5] = 0;
+    if ((running + 7) / 8 + 8 > im.out_cap) s.status = VP8L_ERR_NO_MEMORY;
+  }
+}
+
+constexpr uint32_t kWinWords = 4096;  // LDS staging window: 16 KiB = 131072 stream bits
+
+struct StagePut {
+  uint32_t *stage;
+  long long rel;  // bit position relative to the window start (may be negative / beyond)
+  __device__ __forceinline__ void operator()(uint32_t v, uint32_t n) {
+    constexpr long long kWinBits = (long long)kWinWords * 32;
+    long long r = rel;
+    rel += n;
+    if (n == 0 || r + (long long)n <= 0 || r >= kWinBits) return;
+    unsigned long long val = v;
+    int nn = (int)n;
+    if (r < 0) { val >>= (int)(-r); nn += (int)r; r = 0; }
+    if (r + nn > kWinBits) { nn = (int)(kWinBits - r); val &= (1ull << nn) - 1ull; }
+    const uint32_t w = (uint32_t)(r >> 5), sh = (uint32_t)(r & 31);
+    val <<= sh;
+    atomicOr(&stage[w], (uint32_t)val);
+    const uint32_t hi = (uint32_t)(val >> 32);
+    if (hi) atomicOr(&stage[w + 1], hi);
+  }
+};
+
+__global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                              const uint32_t *__restrict__ sb_first, uint32_t n,
+                                              const uint32_t *__restrict__ pix, const uint32_t *__restrict__ match,
+                                              const uint32_t *__restrict__ flags, const CodeTables *__restrict__ tables,
+                                              const uint32_t *__restrict__ unit_bits, const uint64_t *__restrict__ unit_off,
+                                              uint8_t *__restrict__ out) {
+  __shared__ CodeTables tab;
+  __shared__ uint32_t stage[kWinWords + 2];
+  __shared__ uint32_t wsum[4];
+  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  if (st[img].status != 0) return;
+  const uint32_t M = st[img].M, xsize = st[img].xsize;
+  const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
+  if (p0 >= M) return;
+  const uint32_t total = unit_bits[unit];
+  if (total == 0) return;
+  load_tables(tab, &tables[img], tid);
+  const EncImage im = imgs[img];
+  const uint64_t pos0 = im.pos0;
+  // this thread's 16 consecutive positions
+  const uint32_t pb = p0 + tid * 16;
+  uint32_t mt[16];
+  uint32_t fl = 0;
+  if (pb < M) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(match + pos0 + pb);
+    const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];  // the region has readable slack past M
+    const uint32_t L[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+    for (int i = 0; i < 16; i++) mt[i] = L[i];
+    fl = (flags[(pos0 + pb) >> 5] >> ((pos0 + pb) & 31)) & 0xffffu;
+    if (pb + 16 > M) fl &= (1u << (M - pb)) - 1u;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; i++) mt[i] = 0;
+  }
+  __syncthreads();
+  CountPut cnt;
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+    if ((fl >> i) & 1u) {
+      const uint32_t len = mt[i] & 0xff;
+      emit_token(cnt, tab, len ? 0u : pix[pos0 + pb + i], len, (mt[i] >> 8) & 0x7ff, xsize);
+    }
+  const uint32_t incl = wave_incl_scan_u32(cnt.bits, (int)lane);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t k = 0; k < wave; k++) before += wsum[k];
+  const uint64_t start_bit = unit_off[unit], end_bit = start_bit + total;
+  const uint64_t my_bit = start_bit + before + incl - cnt.bits;
+  const uint64_t first_word = start_bit >> 5, last_word = (end_bit - 1) >> 5;
+  const uint64_t nwords = last_word - first_word + 1;
+  uint32_t *out32 = reinterpret_cast<uint32_t *>(out + im.out_off);
+  for (uint64_t wbase = 0; wbase < nwords; wbase += kWinWords) {
+    for (uint32_t i = tid; i < kWinWords + 2; i += 256) stage[i] = 0;
+    __syncthreads();
+    StagePut put{stage, (long long)my_bit - (long long)((first_word + wbase) << 5)};
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      if ((fl >> i) & 1u) {
+        const uint32_t len = mt[i] & 0xff;
+        emit_token(put, tab, len ? 0u : pix[pos0 + pb + i], len, (mt[i] >> 8) & 0x7ff, xsize);
+      }
+    __syncthreads();
+    const uint64_t cntw = nwords - wbase < kWinWords ? nwords - wbase : kWinWords;
+    for (uint32_t i = tid; i < cntw; i += 256) {
+      const uint64_t gw = first_word + wbase + i;
+      // a word is shared with the neighbouring unit (or the header) when a unit boundary falls inside it
+      const bool shared = (gw == first_word && (start_bit & 31)) || (gw == last_word && (end_bit & 31));
+      if (shared) atomicOr(&out32[gw], stage[i]); else out32[gw] = stage[i];
+    }
+    __syncthreads();
+  }
+}
+
+// =============================================================================================
+// Synthetic images on the device: x(k) = k-th state of the 32-bit LCG reached by jumping ahead.
+// =============================================================================================
+__device__ __forceinline__ uint32_t clamp_u8(int v) { return v < 0 ? 0u : v > 255 ? 255u : (uint32_t)v; }
+
+__device__ __forceinline__ uint32_t lcg_state(uint32_t seed, uint64_t k) {  // state after k steps
+  uint32_t ra = 1, rc = 0, ba = 1664525u, bc = 1013904223u;
+  while (k) {
+    if (k & 1) { rc = ba * rc + bc; ra = ba * ra; }
+    bc = ba * bc + bc;
+    ba = ba * ba;
+    k >>= 1;
+  }
+  return ra * seed + rc;
+}
+
+__global__ __launch_bounds__(256) void k_generate(int mode, uint32_t w, uint32_t h, uint32_t seed, uint32_t ncolors,
+                                                  uint32_t *__restrict__ out) {
+  __shared__ uint32_t pal[256];
+  if (mode == 5) {
+    if (threadIdx.x < ncolors) pal[threadIdx.x] = 0xff000000u | ((lcg_state(777u, threadIdx.x + 1) >> 8) & 0xffffffu);
+    __syncthreads();
+  }
+  const uint64_t npx = (uint64_t)w * h;
+  const uint32_t dw = w > 1 ? w - 1 : 1, dh = h > 1 ? h - 1 : 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (uint64_t)gridDim.x * 256) {
+    const uint32_t x = (uint32_t)(i % w), y = (uint32_t)(i / w);
+    uint32_t p;
+    if (mode == 3) {
+      uint32_t s = lcg_state(seed, 6 * i);
+      int nz[3];
+      for (int c = 0; c < 3; c++) {
+        s = s * 1664525u + 1013904223u; const uint32_t a = s >> 8;
+        s = s * 1664525u + 1013904223u; const uint32_t b = s >> 8;
+        nz[c] = (int)(a & 3) + (int)(b & 3) - 3;
+      }
+      const int L = (int)(x * 160 / dw + y * 80 / dh);
+      p = 0xff000000u | (clamp_u8(L + 10 + nz[0]) << 16) | (clamp_u8(L + nz[1]) << 8) | clamp_u8(L * 3 / 4 + 5 + nz[2]);
+    } else if (mode == 4) {
+      const uint32_t bs = ((y / 16) * 7919u + (x / 16) * 104729u) * 2654435761u;
+      p = 0xff000000u | ((bs >> 8) & 0xf0f0f0u);
+      if (((lcg_state(seed, i + 1) >> 8) & 31) == 0) p ^= 0x00010101u;
+    } else {
+      const uint32_t l = lcg_state(seed, i + 1) >> 8;
+      p = pal[((x / 7) * 13 + (y / 5) * 31 + ((l & 15) == 0)) % ncolors];
+    }
+    out[i] = p;
+  }
+}
+
+}  // namespace vp8l
+
+// =============================================================================================
+// Host side: batch encoder context
+// =============================================================================================
+using namespace vp8l;
+
+struct vp8l_encoder {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[10] = {};
+  std::mutex mu;
+  // workspace (grown on demand)
+  DeviceBuffer d_imgs, d_state, d_sbfirst, d_gsets, d_pix, d_match, d_flags, d_histo, d_tables, d_sx, d_entry,
+      d_unit_bits, d_unit_off;
+  // last batch
+  std::vector<EncImage> imgs;
+  std::vector<EncState> states;
+  std::vector<uint32_t> sb_first;
+  uint8_t *last_out = nullptr;
+  double last_seconds = 0;
+  double stage_seconds[8] = {};
+};
+
+extern "C" size_t vp8l_encode_bound(uint32_t w, uint32_t h) {
+  // a Huffman code never spends more than a fixed-length code would: <= 9+8+8+8 bits per literal,
+  // <= 9+5+6+9 per match, at most one token per pixel; plus headers and the palette sub-image
+  const uint64_t px = (uint64_t)w * h;
+  return (size_t)(((px * 33 + 7) / 8 + 16384 + 255) & ~(uint64_t)255);
+}
+
+extern "C" int vp8l_encoder_create(int device, vp8l_encoder **out) {
+  if (!out) return VP8L_ERR_BAD_ARGUMENT;
+  int rc = select_device(device, &device);
+  if (rc != VP8L_OK) return rc;
+  vp8l_encoder *e = new (std::nothrow) vp8l_encoder;
+  if (!e) return VP8L_ERR_NO_MEMORY;
+  e->device = device;
+  if (!hip_ok(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete e; return VP8L_ERR_HIP; }
+  for (auto &ev : e->ev)
+    if (!hip_ok(hipEventCreate(&ev), "hipEventCreate")) { vp8l_encoder_destroy(e); return VP8L_ERR_HIP; }
+  *out = e;
+  return VP8L_OK;
+}
+
+extern "C" void vp8l_encoder_destroy(vp8l_encoder *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  DeviceBuffer *bufs[] = {&e->d_imgs, &e->d_state, &e->d_sbfirst, &e->d_gsets, &e->d_pix, &e->d_match, &e->d_flags,
+                          &e->d_histo, &e->d_tables, &e->d_sx, &e->d_entry, &e->d_unit_bits, &e->d_unit_off};
+  for (auto *b : bufs) b->release();
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint32_t *const *d_argb, const uint32_t *width,
+                                          const uint32_t *height, uint8_t *d_out, size_t out_cap, size_t *out_offset,
+                                          size_t *out_len, int *status) {
+  if (!e || !d_argb || !width || !height || !d_out || !out_offset || !out_len || !status) return VP8L_ERR_BAD_ARGUMENT;
+  if (n == 0) return VP8L_OK;
+  if (n > 0x7fffffffu) return VP8L_ERR_BAD_ARGUMENT;
+  if (((uintptr_t)d_out & 255) != 0) return VP8L_ERR_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lock(e->mu);
+  if (!hip_ok(hipSetDevice(e->device), "hipSetDevice")) return VP8L_ERR_HIP;
+
+  // ---- layout (host) -----------------------------------------------------------------------
+  e->imgs.assign(n, EncImage{});
+  e->sb_first.assign(n + 1, 0);
+  e->states.assign(n, EncState{});
+  uint64_t sb_total = 0, out_used = 0;
+  std::vector<uint32_t> live;  // images that passed the argument checks (vp8l.h:587-590)
+  for (size_t i = 0; i < n; i++) {
+    status[i] = VP8L_OK;
+    out_offset[i] = 0;
+    out_len[i] = 0;
+    if (!d_argb[i] || width[i] == 0 || height[i] == 0) { status[i] = VP8L_ERR_INVALID_ARGB; continue; }
+    if (width[i] > kMaxDim || height[i] > kMaxDim) { status[i] = VP8L_ERR_TOO_BIG_ARGB; continue; }
+    live.push_back((uint32_t)i);
+  }
+  const uint32_t nl = (uint32_t)live.size();
+  if (nl == 0) return VP8L_OK;
+  for (uint32_t k = 0; k < nl; k++) {
+    const size_t i = live[k];
+    const uint64_t px = (uint64_t)width[i] * height[i];
+    EncImage &im = e->imgs[k];
+    im.argb = d_argb[i];
+    im.w = width[i];
+    im.h = height[i];
+    im.pos0 = sb_total * kSuper;
+    im.out_off = out_used;
+    im.out_cap = vp8l_encode_bound(width[i], height[i]);
+    e->sb_first[k] = (uint32_t)sb_total;
+    sb_total += (px + kTailPad + kSuper - 1) / kSuper;
+    out_used += im.out_cap;
+    if (out_used > out_cap) return VP8L_ERR_NO_MEMORY;
+    if (sb_total > 0x3fffffffu) return VP8L_ERR_NO_MEMORY;
+    out_offset[i] = (size_t)im.out_off;
+  }
+  e->sb_first[nl] = (uint32_t)sb_total;
+  const uint64_t npos = sb_total * kSuper;
+  const uint64_t nunits = sb_total * kUnitsPerSuper;
+
+  // ---- workspace ---------------------------------------------------------------------------
+  bool ok = e->d_imgs.reserve(nl * sizeof(EncImage)) && e->d_state.reserve(nl * sizeof(EncState)) &&
+            e->d_sbfirst.reserve((nl + 1) * sizeof(uint32_t)) &&
+            e->d_gsets.reserve((size_t)nl * kSetSlots * sizeof(unsigned long long)) &&
+            e->d_pix.reserve(npos * 4) && e->d_match.reserve(npos * 4) && e->d_flags.reserve(npos / 8) &&
+            e->d_histo.reserve((size_t)nl * kNumCodes * kCodeStride * 4) && e->d_tables.reserve((size_t)nl * sizeof(CodeTables)) &&
+            e->d_sx.reserve(sb_total * kBlockLen) && e->d_entry.reserve(sb_total) &&
+            e->d_unit_bits.reserve(nunits * 4) && e->d_unit_off.reserve(nunits * 8);
+  if (!ok) return VP8L_ERR_NO_MEMORY;
+
+  hipStream_t s = e->stream;
+  auto *imgs = e->d_imgs.as<EncImage>();
+  auto *st = e->d_state.as<EncState>();
+  auto *sbf = e->d_sbfirst.as<uint32_t>();
+  auto *gsets = e->d_gsets.as<unsigned long long>();
+  auto *pix = e->d_pix.as<uint32_t>();
+  auto *match = e->d_match.as<uint32_t>();
+  auto *flags = e->d_flags.as<uint32_t>();
+  auto *histo = e->d_histo.as<uint32_t>();
+  auto *tables = e->d_tables.as<CodeTables>();
+  auto *sx = e->d_sx.as<uint8_t>();
+  auto *entry = e->d_entry.as<uint8_t>();
+  auto *ubits = e->d_unit_bits.as<uint32_t>();
+  auto *uoff = e->d_unit_off.as<uint64_t>();
+
+  bool h = true;
+  h = h && hip_ok(hipMemcpyAsync(imgs, e->imgs.data(), nl * sizeof(EncImage), hipMemcpyHostToDevice, s), "upload images");
+  h = h && hip_ok(hipMemcpyAsync(sbf, e->sb_first.data(), (nl + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s), "upload table");
+  h = h && hip_ok(hipMemsetAsync(st, 0, nl * sizeof(EncState), s), "clear state");
+  h = h && hip_ok(hipMemsetAsync(gsets, 0xff, (size_t)nl * kSetSlots * sizeof(unsigned long long), s), "clear sets");
+  h = h && hip_ok(hipMemsetAsync(histo, 0, (size_t)nl * kNumCodes * kCodeStride * 4, s), "clear histograms");
+  if (!h) return VP8L_ERR_HIP;
+
+  const uint32_t gsb = (uint32_t)sb_total, gunits = (uint32_t)nunits;
+  (void)hipEventRecord(e->ev[0], s);
+  hipLaunchKernelGGL(k_palette_scan, dim3(gsb), dim3(256), 0, s, imgs, st, sbf, nl, gsets);
+  hipLaunchKernelGGL(k_palette_finalize, dim3(nl), dim3(256), 0, s, imgs, st, gsets);
+  (void)hipEventRecord(e->ev[1], s);
+  hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix);
+  (void)hipEventRecord(e->ev[2], s);
+  hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match);
+  (void)hipEventRecord(e->ev[3], s);
+  hipLaunchKernelGGL(k_parse_exits, dim3(gsb), dim3(128), 0, s, imgs, st, sbf, nl, match, sx);
+  hipLaunchKernelGGL(k_parse_chain, dim3(nl), dim3(256), 0, s, st, sbf, sx, entry);
+  hipLaunchKernelGGL(k_parse_mark, dim3(gsb), dim3(128), 0, s, imgs, st, sbf, nl, match, entry, flags);
+  (void)hipEventRecord(e->ev[4], s);
+  hipLaunchKernelGGL(k_histogram, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, histo);
+  (void)hipEventRecord(e->ev[5], s);
+  hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(64), 0, s, imgs, st, histo, tables, d_out);
+  (void)hipEventRecord(e->ev[6], s);
+  hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, ubits);
+  hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, imgs, st, sbf, ubits, uoff, d_out);
+  (void)hipEventRecord(e->ev[7], s);
+  hipLaunchKernelGGL(k_emit, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, ubits, uoff, d_out);
+  (void)hipEventRecord(e->ev[8], s);
+  if (!hip_ok(hipGetLastError(), "kernel launch")) return VP8L_ERR_HIP;
+  if (!hip_ok(hipMemcpyAsync(e->states.data(), st, nl * sizeof(EncState), hipMemcpyDeviceToHost, s), "download state")) return VP8L_ERR_HIP;
+  if (!hip_ok(hipStreamSynchronize(s), "encode batch")) return VP8L_ERR_HIP;
+
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e->ev[0], e->ev[8]);
+  e->last_seconds = ms * 1e-3;
+  for (int k = 0; k < 8; k++) {
+    ms = 0;
+    (void)hipEventElapsedTime(&ms, e->ev[k], e->ev[k + 1]);
+    e->stage_seconds[k] = ms * 1e-3;
+  }
+  e->last_out = d_out;
+  for (uint32_t k = 0; k < nl; k++) {
+    const size_t i = live[k];
+    status[i] = e->states[k].status;
+    if (status[i] == VP8L_OK) out_len[i] = (size_t)((e->states[k].total_bits + 7) / 8);
+  }
+  // keep `imgs` indexable by the caller's image number for fetch_stage
+  if (nl != n) {
+    std::vector<EncImage> byidx(n, EncImage{});
+    std::vector<EncState> stidx(n, EncState{});
+    for (uint32_t k = 0; k < nl; k++) { byidx[live[k]] = e->imgs[k]; stidx[live[k]] = e->states[k]; }
+    e->imgs.swap(byidx);
+    e->states.swap(stidx);
+  }
+  return VP8L_OK;
+}
+
+extern "C" long vp8l_encoder_fetch_stage(vp8l_encoder *e, size_t image, int what, void *host_buf, size_t cap) {
+  if (!e || !host_buf) return VP8L_ERR_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lock(e->mu);
+  if (image >= e->imgs.size() || e->imgs[image].argb == nullptr) return VP8L_ERR_BAD_ARGUMENT;
+  if (!hip_ok(hipSetDevice(e->device), "hipSetDevice")) return VP8L_ERR_HIP;
+  const EncImage &im = e->imgs[image];
+  const EncState &st = e->states[image];
+  // index of this image among the live ones = its slot in the device tables
+  size_t slot = 0;
+  for (size_t i = 0; i < image; i++) slot += e->imgs[i].argb != nullptr;
+  const void *src = nullptr;
+  size_t bytes = 0;
+  uint32_t info[4];
+  switch (what) {
+    case VP8L_STAGE_RESIDUAL: src = e->d_pix.as<uint32_t>() + im.pos0; bytes = (size_t)st.M * 4; break;
+    case VP8L_STAGE_MATCH: src = e->d_match.as<uint32_t>() + im.pos0; bytes = (size_t)st.M * 4; break;
+    case VP8L_STAGE_HISTO: src = e->d_histo.as<uint32_t>() + slot * kNumCodes * kCodeStride; bytes = kNumCodes * kCodeStride * 4; break;
+    case VP8L_STAGE_CODELEN: src = e->d_tables.as<CodeTables>()[slot].len; bytes = kNumCodes * kCodeStride; break;
+    case VP8L_STAGE_INFO:
+      info[0] = st.ncolors; info[1] = st.bits; info[2] = st.xsize; info[3] = st.M;
+      if (cap < sizeof(info)) return VP8L_ERR_BAD_ARGUMENT;
+      memcpy(host_buf, info, sizeof(info));
+      return (long)sizeof(info);
+    default: return VP8L_ERR_BAD_ARGUMENT;
+  }
+  if (bytes > cap) return VP8L_ERR_BAD_ARGUMENT;
+  if (!hip_ok(hipMemcpy(host_buf, src, bytes, hipMemcpyDeviceToHost), "fetch stage")) return VP8L_ERR_HIP;
+  if (what == VP8L_STAGE_MATCH) {
+    // fold the parse flags (kept as a bit array on the device) into bit 31
+    std::vector<uint32_t> fl((st.M + 31) / 32);
+    if (!hip_ok(hipMemcpy(fl.data(), e->d_flags.as<uint32_t>() + im.pos0 / 32, fl.size() * 4, hipMemcpyDeviceToHost), "fetch flags"))
+      return VP8L_ERR_HIP;
+    uint32_t *m = static_cast<uint32_t *>(host_buf);
+    for (uint32_t p = 0; p < st.M; p++) m[p] |= ((fl[p >> 5] >> (p & 31)) & 1u) << 31;
+  }
+  return (long)bytes;
+}
+
+extern "C" double vp8l_encoder_last_device_seconds(const vp8l_encoder *e) { return e ? e->last_seconds : 0.0; }
+
+extern "C" int vp8l_encoder_last_stage_seconds(const vp8l_encoder *e, double *seconds, int cap) {
+  if (!e || !seconds) return VP8L_ERR_BAD_ARGUMENT;
+  const int k = cap < 8 ? cap : 8;
+  for (int i = 0; i < k; i++) seconds[i] = e->stage_seconds[i];
+  return k;
+}
+
+extern "C" int vp8l_generate_device(int device, int mode, uint32_t w, uint32_t h, uint32_t seed, uint32_t ncolors, uint32_t *d_argb) {
+  if (!d_argb || w == 0 || h == 0 || mode < 3 || mode > 5) return VP8L_ERR_BAD_ARGUMENT;
+  int rc = select_device(device, &device);
+  if (rc != VP8L_OK) return rc;
+  if (mode == 5 && (ncolors == 0 || ncolors > 256)) ncolors = 200;
+  const uint64_t npx = (uint64_t)w * h;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((npx + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_generate, dim3(grid), dim3(256), 0, 0, mode, w, h, seed, ncolors, d_argb);
+  if (!hip_ok(hipGetLastError(), "k_generate")) return VP8L_ERR_HIP;
+  if (!hip_ok(hipDeviceSynchronize(), "k_generate")) return VP8L_ERR_HIP;
+  return VP8L_OK;
+}
