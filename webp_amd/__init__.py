@@ -14,6 +14,10 @@ import os
 
 import numpy as np
 
+# PyTorch bundles its own HIP runtime (same soname as /opt/rocm's).  Two HIP runtimes in one
+# process cannot both own the GPU, so torch's is loaded FIRST and this library then binds to it.
+import torch  # noqa: F401  (device memory, streams and torch.distributed come from it anyway)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvp8l_amd.so")
 
