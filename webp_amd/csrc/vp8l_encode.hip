@@ -188,11 +188,77 @@ __global__ __launch_bounds__(256) void k_transform(const EncImage *__restrict__ 
 // kept relative to the chunk (pos - P + 16, P = last position of the chunk) so every per-step
 // constant is a small literal.
 // =============================================================================================
+// max over the 64 lanes with DPP lane moves fused into the max (no LDS round trips); the result
+// is read from lane 63 into an SGPR.  Each step reads the register the previous VALU instruction
+// wrote, which needs two wait states in front of a DPP operand.
+#define VP8L_DPP_MAX(v, ctrl) asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 " ctrl : "+v"(v))
+__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v) {
+  VP8L_DPP_MAX(v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+  VP8L_DPP_MAX(v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+  VP8L_DPP_MAX(v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+  VP8L_DPP_MAX(v, "row_mirror row_mask:0xf bank_mask:0xf");   // every lane of a 16-lane row holds the row's max
+  VP8L_DPP_MAX(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");  // rows 1 and 3 also take the row before
+  VP8L_DPP_MAX(v, "row_bcast:31 row_mask:0xc bank_mask:0xf");  // rows 2 and 3 take lane 31: lane 63 = wave max
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ void load16(const uint32_t *__restrict__ src, uint32_t (&L)[16]) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(src);
+  const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+  L[0] = v0.x; L[1] = v0.y; L[2] = v0.z; L[3] = v0.w; L[4] = v1.x; L[5] = v1.y; L[6] = v1.z; L[7] = v1.w;
+  L[8] = v2.x; L[9] = v2.y; L[10] = v2.z; L[11] = v2.w; L[12] = v3.x; L[13] = v3.y; L[14] = v3.z; L[15] = v3.w;
+}
+
+// One chunk of 16 positions P, P-1, .., P-15 (P = 15 mod 16).  EMIT: the positions belong to the
+// tile (best matches are produced); otherwise they only warm the run state up.
+// One "slot" = the 64 cells (lanes) of one j.  Most slots of natural images hold no equal pixel:
+// their compare mask is empty, every run of the slot ends here and nothing can match, so the slot
+// costs one compare and one move.  The test is on the scalar (wave-uniform) compare mask.
+template <bool HEAD, bool EMIT>
+__device__ __forceinline__ uint32_t lz77_chunk(uint32_t (&mis)[16], const uint32_t (&win)[31], const uint32_t (&cap)[31],
+                                               const uint32_t xcur, const int P, const uint32_t M, const int lane) {
+  uint32_t res = 0;  // lane s: packed (end of best match << 10 | distance-1) of position P-s
+#pragma unroll
+  for (int s = 0; s < 16; s++) {
+    const uint32_t p = (uint32_t)(P - s);
+    if (p >= M) continue;  // past the end of the image (last chunk only)
+    const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xcur, 15 - s);  // data[p], the same for all lanes
+    const uint32_t here = 16u - (uint32_t)s;
+    const uint32_t lim = here + kMaxLen;  // at most 128 pixels
+    uint32_t key = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      bool eq = win[s + j] == x;
+      if (HEAD) eq = eq && (uint32_t)(16 * lane + j + 1) <= p;  // distances reaching before the first pixel never match
+      mis[j] = eq ? mis[j] : here;
+      if (EMIT && __builtin_expect(__ballot(eq) != 0, 0)) {
+        uint32_t t = mis[j] < cap[j - s + 15] ? mis[j] : cap[j - s + 15];
+        t = t < lim ? t : lim;
+        const uint32_t kj = (t << 4) | (uint32_t)j;
+        key = key > kj ? key : kj;
+      }
+    }
+    if (EMIT) {
+      // (end of match, distance-1): the largest distance wins among equal lengths (lz77.h:68).
+      // key == 0: no equal pixel anywhere in the window, length 0.
+      uint32_t K = (here << 10);
+      if (__builtin_expect(__ballot(key != 0) != 0, 1)) {
+        K = ((key & ~15u) << 6) | ((uint32_t)lane << 4) | (key & 15u);
+        K = wave_max_dpp(K);
+        if (K < (here << 10)) K = here << 10;
+      }
+      res = lane == s ? K : res;
+    }
+  }
+  return res;
+}
+
+// a, b, M are wave-uniform (scalar registers).
 template <bool HEAD>
 __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uint32_t *__restrict__ match, const uint32_t M,
                                           const uint32_t a, const uint32_t b, const int lane) {
   const uint32_t qs = (b + 127 < M - 1) ? b + 127 : M - 1;
-  int ctop = (int)(qs >> 4);
+  const int ctop = (int)(qs >> 4);
   const int cbot = (int)(a >> 4);
   int P = ctop * 16 + 15;
   uint32_t mis[16];  // per distance: first mismatch position at or after the current one (chunk relative)
@@ -205,73 +271,44 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
 #pragma unroll
   for (int k = 0; k < 31; k++) cap[k] = 16u * (uint32_t)lane + 2u + (uint32_t)k;
   uint32_t win[31];  // win[k] = data[P - 16*lane - 1 - k]
+  uint32_t nxt[16];  // the 16 pixels that enter the window with the next chunk (loaded one chunk ahead)
+  uint32_t xnext;    // lane k (< 16): pixel P-15+k of the next chunk
+#pragma unroll
+  for (int i = 0; i < 16; i++) nxt[i] = 0;
   {
     const int a1 = P - 16 * lane - 15;  // 16 aligned pixels, the last one (distance 0) unused
-    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
-    if (!HEAD || a1 >= 0) {
-      const uint4 *src = reinterpret_cast<const uint4 *>(data + a1);
-      v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3];
-    }
-    const uint32_t L[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+    uint32_t L[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) L[i] = 0;
+    if (!HEAD || a1 >= 0) load16(data + a1, L);
 #pragma unroll
     for (int i = 0; i < 15; i++) win[14 - i] = L[i];
+    const int a0 = P - 16 * lane - 31;
+    if (!HEAD || a0 >= 0) load16(data + a0, nxt);
+    xnext = data[P - 15 + (lane & 15)];
   }
   for (int ck = ctop; ck >= cbot; ck--, P -= 16) {
-    {
-      const int a0 = P - 16 * lane - 31;
-      uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
-      if (!HEAD || a0 >= 0) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(data + a0);
-        v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3];
-      }
-      const uint32_t L[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
 #pragma unroll
-      for (int i = 0; i < 16; i++) win[30 - i] = L[i];
+    for (int i = 0; i < 16; i++) win[30 - i] = nxt[i];
+    const uint32_t xcur = xnext;
+    if (ck > cbot) {  // prefetch for the chunk below
+      const int a0 = P - 16 - 16 * lane - 31;
+      if (!HEAD || a0 >= 0) load16(data + a0, nxt);
+      xnext = data[P - 31 + (lane & 15)];
     }
-    uint32_t X[16];  // the 16 pixels of this chunk, the same in every lane
-    {
-      const uint4 *src = reinterpret_cast<const uint4 *>(data + (P - 15));
-      const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-      const uint32_t L[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-#pragma unroll
-      for (int i = 0; i < 16; i++) X[15 - i] = L[i];
-    }
-    uint32_t res = 0;
-    const bool writes = (uint32_t)(P - 15) < b;
-#pragma unroll
-    for (int s = 0; s < 16; s++) {
-      const uint32_t p = (uint32_t)(P - s);
-      if (p >= M) continue;  // past the end of the image (last chunk only)
-      const uint32_t x = X[s];
-      const uint32_t here = 16u - (uint32_t)s;
-#pragma unroll
-      for (int j = 0; j < 16; j++) mis[j] = (win[s + j] == x) ? mis[j] : here;
-      if (HEAD) {  // distances that reach before the first pixel never match
-#pragma unroll
-        for (int j = 0; j < 16; j++) mis[j] = ((uint32_t)(16 * lane + j + 1) > p) ? here : mis[j];
-      }
-      if (p < b) {
-        const uint32_t lim = here + kMaxLen;  // at most 128 pixels
-        uint32_t key = 0;
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-          uint32_t t = mis[j] < cap[j - s + 15] ? mis[j] : cap[j - s + 15];
-          t = t < lim ? t : lim;
-          const uint32_t kj = (t << 4) | (uint32_t)j;
-          key = key > kj ? key : kj;
+    if ((uint32_t)(P - 15) < b) {
+      const uint32_t res = lz77_chunk<HEAD, true>(mis, win, cap, xcur, P, M, lane);
+      if (lane < 16) {
+        const uint32_t p = (uint32_t)(P - lane);
+        if (p < b && p < M) {
+          uint32_t len = (res >> 10) - (16u - (uint32_t)lane);
+          const uint32_t dist = (res & 1023u) + 1u;
+          if (p == M - 1) len = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
+          match[p] = len ? (len | (dist << 8)) : 0u;
         }
-        // (end of match, distance-1): the largest distance wins among equal lengths (lz77.h:68)
-        uint32_t K = ((key & ~15u) << 6) | ((uint32_t)lane << 4) | (key & 15u);
-        K = wave_max_u32(K);
-        uint32_t len = (K >> 10) - here;
-        const uint32_t dist = (K & 1023u) + 1u;
-        if (p == M - 1) len = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
-        if (lane == s) res = len ? (len | (dist << 8)) : 0u;
       }
-    }
-    if (writes && lane < 16) {
-      const uint32_t p = (uint32_t)(P - lane);
-      if (p < b && p < M) match[p] = res;
+    } else {
+      (void)lz77_chunk<HEAD, false>(mis, win, cap, xcur, P, M, lane);
     }
 #pragma unroll
     for (int k = 0; k < 15; k++) win[k] = win[k + 16];
@@ -285,9 +322,10 @@ __global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs,
                                               const uint32_t *__restrict__ pix, uint32_t *__restrict__ match) {
   constexpr uint32_t kPerSuper = kSuper / kLzBlock;
   const uint32_t blk = blockIdx.x, sb = blk / kPerSuper, img = find_image(sb_first, n, sb);
-  const uint32_t M = st[img].M;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t a = (blk - sb_first[img] * kPerSuper) * kLzBlock + (uint32_t)wave * kLzTile;
+  const uint32_t M = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[img].M);
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t a = (blk - sb_first[img] * kPerSuper) * kLzBlock + wave * kLzTile;
   if (a >= M) return;
   const uint32_t b = a + kLzTile < M ? a + kLzTile : M;
   const uint64_t pos0 = imgs[img].pos0;
