@@ -27,18 +27,10 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import webp_amd  # noqa: E402
+from webp_amd import sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 LZ77_BYTES_PER_PIXEL = 8.0     # 4 B pixel read + 4 B (length, distance) written per coded pixel
-
-
-def image_plan(batch, rank):
-    """(mode, seed) of image k of this rank's batch."""
-    plan = []
-    for k in range(batch):
-        g = rank * batch + k
-        plan.append((4 if g % 4 == 3 else 3, 12345 + g))
-    return plan
 
 
 def cpu_baseline(w, h, plan, threads, budget_images):
@@ -90,7 +82,7 @@ def main():
 
     w, h, batch = args.width, args.height, args.batch
     npx = w * h
-    plan = image_plan(batch, rank)
+    plan = sharding.bench_image_plan(batch, rank)
 
     # ---- inputs resident in HBM (generated on the device) -------------------------------------
     webp_amd.init()
@@ -128,10 +120,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     assert (status == 0).all(), status
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    total_px, elapsed = sharding.global_throughput(batch * npx * args.steps, elapsed, dev)
 
     total_bytes = int(lens.sum())
     bpp = 8.0 * total_bytes / (batch * npx)
@@ -153,7 +142,7 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * batch * npx / 1e6 / (elapsed / args.steps)
+        value = total_px / 1e6 / elapsed
         lz_avg = float(np.mean(lz_times))
         achieved = LZ77_BYTES_PER_PIXEL * batch * npx / lz_avg / 1e9
         traffic = None

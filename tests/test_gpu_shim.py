@@ -1,0 +1,39 @@
+"""The C++ mirror of the reference classes (include/webp_amd/webp.hpp): a C++ program written
+against the reference's interface encodes to a RIFF .webp file and decodes it again; the raw
+stream must equal the oracle's and the container must be the reference's (webp.h:167-173)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(O.ROOT, "tests", "cpp", "shim_test")
+
+
+def expected_image(w, h, mode):
+    y, x = np.mgrid[0:h, 0:w].astype(np.uint32)
+    if mode == 0:
+        img = np.uint32(0xFF000000) | (((x * 7 + y * 3) & 0xFF) << 16) | (((x + y) & 0xFF) << 8) | ((x ^ y) & 0xFF)
+    else:
+        img = np.where(((x // 3 + y // 2) & 1) == 1, np.uint32(0xFF112233), np.uint32(0x80FFEEDD))
+    return img.astype(np.uint32).reshape(-1)
+
+
+@pytest.mark.parametrize("w,h,mode", [(40, 30, 0), (33, 7, 1), (1, 1, 0)])
+def test_cpp_shim_roundtrip_and_container(tmp_path, w, h, mode):
+    assert os.path.exists(EXE), "build first (__graft_entry__.build())"
+    webp, raw = str(tmp_path / "o.webp"), str(tmp_path / "o.vp8l")
+    # torch's bundled HIP runtime is not involved here: a plain C++ process on the system runtime
+    r = subprocess.run([EXE, str(w), str(h), str(mode), webp, raw], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    stream = open(raw, "rb").read()
+    rc, ref = O.encode(expected_image(w, h, mode), w, h)
+    assert rc == 0 and stream == ref
+    blob = open(webp, "rb").read()
+    assert blob[:4] == b"RIFF" and blob[8:16] == b"WEBPVP8L"
+    assert struct.unpack("<I", blob[4:8])[0] == len(stream) + 8
+    assert blob[16:] == stream

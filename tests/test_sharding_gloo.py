@@ -1,0 +1,60 @@
+"""world_size-2 check (gloo, CPU) of the only distributed logic on the path: which rank owns
+which images, and the throughput bookkeeping (sum of pixels, max of seconds)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from webp_amd import sharding
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    owned = list(sharding.shard_indices(11, world, rank))
+    plan = sharding.bench_image_plan(4, rank)
+    px, sec = sharding.global_throughput(1000 * (rank + 1), 0.5 + rank)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, owned)
+    q.put((rank, owned, plan, px, sec, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_partition_and_bookkeeping():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    all_owned = []
+    for rank, owned, plan, px, sec, gathered in res:
+        all_owned += owned
+        assert px == 3000 and sec == 1.5          # sum of pixels, slowest rank
+        assert [i for g in gathered for i in g] == list(range(11))
+        assert plan == [(4 if (rank * 4 + k) % 4 == 3 else 3, 12345 + rank * 4 + k) for k in range(4)]
+    assert sorted(all_owned) == list(range(11))     # every image exactly once, no exchange needed
+    assert abs(len(res[0][1]) - len(res[1][1])) <= 1
+
+
+def test_single_process_is_identity():
+    assert sharding.global_throughput(7, 0.25) == (7, 0.25)
+    assert list(sharding.shard_indices(5, 1, 0)) == [0, 1, 2, 3, 4]
+    assert [len(sharding.shard_indices(10, 4, r)) for r in range(4)] == [3, 3, 2, 2]
