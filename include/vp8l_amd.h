@@ -88,6 +88,14 @@ int vp8l_encoder_encode_device(vp8l_encoder *enc, size_t n, const uint32_t *cons
                                const uint32_t *height, uint8_t *d_out, size_t out_cap, size_t *out_offset,
                                size_t *out_len, int *status);
 
+/* Options.  VP8L_OPT_MATCH_SEARCH: 0 (default) = candidate-list match search with the exhaustive
+ * search as fallback for tiles with heavy duplication; 1 = exhaustive search everywhere.  Both give
+ * identical streams; the option exists for verification and measurement. */
+enum { VP8L_OPT_MATCH_SEARCH = 1 };
+int vp8l_encoder_set_option(vp8l_encoder *enc, int option, int value);
+/* Number of 2048-position tiles of the last call that needed the exhaustive search (and the total). */
+long vp8l_encoder_last_dense_tiles(vp8l_encoder *enc, long *total_tiles);
+
 /* Stage outputs of the LAST encode call on this context, for parity checks of the intermediate
  * planes (copied to host memory).  what: */
 enum {

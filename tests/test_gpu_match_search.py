@@ -1,0 +1,100 @@
+"""The two match-search kernels (candidate lists with fallback / exhaustive) give identical results.
+
+Both are checked per position against the oracle's best match (lz77.h:36-100 restated), on content
+that keeps tiles on the candidate-list path, content that forces the fallback, and mixtures that
+switch inside one image (tile = 2048 coded positions)."""
+import numpy as np
+import pytest
+
+import _oracle as O
+import webp_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def run(img, w, h, exhaustive):
+    import torch
+    enc = webp_amd.Encoder()
+    enc.set_exhaustive_search(exhaustive)
+    d_in = torch.from_numpy(img.view(np.int32)).cuda()
+    cap = enc.bound(w, h)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    off, lens, status = enc.encode_device([d_in.data_ptr()], [w], [h], d_out.data_ptr(), cap)
+    assert status[0] == 0
+    m = enc.fetch_stage(0, webp_amd.STAGE_MATCH)
+    res = enc.fetch_stage(0, webp_amd.STAGE_RESIDUAL)
+    dense, total = enc.last_dense_tiles()
+    data = bytes(d_out[int(off[0]): int(off[0]) + int(lens[0])].cpu().numpy())
+    enc.close()
+    return m, res, dense, total, data
+
+
+def check(img, w, h, expect=None):
+    m0, res, dense, total, s0 = run(img, w, h, False)
+    m1, _, dense1, total1, s1 = run(img, w, h, True)
+    assert dense1 == total1 == total
+    ln, ds = O.lz77_best_all(res)
+    for m in (m0, m1):
+        assert np.array_equal(m & 0xFF, ln)
+        assert np.array_equal(np.where(ln > 0, (m >> 8) & 0x7FF, 0), ds)
+    assert s0 == s1
+    rc, ref = O.encode(img, w, h)
+    assert rc == 0 and s0 == ref
+    if expect == "sparse":
+        assert dense == 0, (dense, total)
+    elif expect == "dense":
+        assert dense == total, (dense, total)
+    elif expect == "mixed":
+        assert 0 < dense < total, (dense, total)
+    return dense, total
+
+
+def test_photo_like_stays_on_candidate_lists():
+    check(O.gen_image(3, 256, 96, 11), 256, 96, "sparse")
+
+
+def test_flat_needs_exhaustive():
+    check(np.full(300 * 40, 0xFF336699, dtype=np.uint32), 300, 40, "dense")
+    check(O.gen_image(5, 256, 64, 3, 2), 256, 64, None)
+
+
+def test_switch_inside_one_image():
+    rng = np.random.default_rng(17)
+    w, h = 512, 48                      # 24576 positions = 12 tiles
+    img = rng.integers(0, 1 << 24, size=w * h, dtype=np.uint32) | np.uint32(0xFF000000)
+    img[5000:9000] = 0xFF101010         # flat stretch crossing tile borders
+    img[15000:15100] = img[14000:14100]  # long match inside a sparse tile, source in the tile before
+    img[20480:20480 + 128] = img[20480 - 1024:20480 - 1024 + 128]  # distance 1024 exactly at a tile start
+    check(img, w, h, "mixed")
+
+
+def test_sources_in_previous_tile_and_tail():
+    rng = np.random.default_rng(23)
+    n = 2048 * 3 + 77
+    a = rng.integers(0, 1 << 24, size=n, dtype=np.uint32) | np.uint32(0xFF000000)
+    a[2048:2048 + 200] = a[2048 - 1024:2048 - 1024 + 200]   # first position of a tile, farthest source
+    a[4090:4200] = a[3990:4100]                              # match running over a tile border
+    a[-60:] = a[-160:-100]                                   # match ending at the last pixel (kept a literal there)
+    check(a, n, 1, "sparse")
+    check(a, 77, (n // 77), None)
+
+
+@pytest.mark.parametrize("alpha", [2, 4, 16, 64, 256, 4096])
+def test_small_alphabets_around_the_budget(alpha):
+    # duplicate density from "every pixel repeats" to "almost none": crosses the candidate-list work budget
+    rng = np.random.default_rng(alpha)
+    w, h = 640, 40
+    img = (rng.integers(0, alpha, size=w * h).astype(np.uint32) * np.uint32(0x00010203)) | np.uint32(0xFF000000)
+    check(img, w, h)
+
+
+def test_periodic_patterns():
+    for period in (1, 2, 3, 7, 16, 100, 1000, 1024, 1025):
+        rng = np.random.default_rng(period)
+        base = rng.integers(0, 1 << 24, size=period, dtype=np.uint32) | np.uint32(0xFF000000)
+        img = np.tile(base, 9000 // period + 1)[:9000]
+        check(img, 9000, 1)
+
+
+def test_graphics_generator():
+    check(O.gen_image(4, 640, 64, 9), 640, 64)

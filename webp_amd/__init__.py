@@ -76,6 +76,9 @@ def lib():
                                                  C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vp8l_encoder_fetch_stage.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
         L.vp8l_encoder_fetch_stage.restype = C.c_long
+        L.vp8l_encoder_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.vp8l_encoder_last_dense_tiles.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+        L.vp8l_encoder_last_dense_tiles.restype = C.c_long
         L.vp8l_encoder_last_device_seconds.argtypes = [C.c_void_p]
         L.vp8l_encoder_last_device_seconds.restype = C.c_double
         L.vp8l_encoder_last_stage_seconds.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -96,7 +99,8 @@ EXPORTED_SYMBOLS = (
     "vp8l_encode_batch", "vp8l_decode_batch", "vp8l_encoder_create", "vp8l_encoder_destroy", "vp8l_encode_bound",
     "vp8l_encoder_encode_device", "vp8l_encoder_fetch_stage", "vp8l_decoder_create", "vp8l_decoder_destroy",
     "vp8l_decoder_decode_device", "vp8l_encoder_last_device_seconds", "vp8l_encoder_last_stage_seconds",
-    "vp8l_decoder_last_device_seconds", "vp8l_generate_device",
+    "vp8l_decoder_last_device_seconds", "vp8l_generate_device", "vp8l_encoder_set_option",
+    "vp8l_encoder_last_dense_tiles",
 )
 
 
@@ -248,6 +252,19 @@ class Encoder:
 
     def last_device_seconds(self):
         return lib().vp8l_encoder_last_device_seconds(self._h)
+
+    def set_exhaustive_search(self, on):
+        """True: test all 1024 distances everywhere; False (default): candidate lists + fallback."""
+        rc = lib().vp8l_encoder_set_option(self._h, 1, 1 if on else 0)
+        if rc != OK:
+            raise Vp8lError(rc, "vp8l_encoder_set_option")
+
+    def last_dense_tiles(self):
+        total = C.c_long()
+        dense = lib().vp8l_encoder_last_dense_tiles(self._h, C.byref(total))
+        if dense < 0:
+            raise Vp8lError(int(dense), "vp8l_encoder_last_dense_tiles")
+        return int(dense), int(total.value)
 
     def last_stage_seconds(self):
         buf = (C.c_double * 8)()

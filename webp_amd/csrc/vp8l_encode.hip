@@ -317,9 +317,110 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
   }
 }
 
+// =============================================================================================
+// Candidate-list form of the same search, for tiles whose window holds few equal pixels (natural
+// images).  The 1024 + 2048 pixels that can be a match source for the tile are bucketed by a hash of
+// the pixel value (counting sort in LDS); a position then looks only at the earlier pixels of its
+// own bucket, keeps those with the same VALUE within 1024 (exactly the distances whose first pixel
+// matches, i.e. every candidate the exhaustive search can score above zero) and extends each by
+// direct comparison.  Work is proportional to the number of equal pairs and their match lengths,
+// so a tile with much duplicate content (flat colour, fine periodic patterns) is abandoned when it
+// exceeds a work budget and is handed to the exhaustive kernel (k_lz77) through `dense_tile`.
+// Both kernels produce identical results; only the time differs.
+// =============================================================================================
+constexpr uint32_t kSpBuckets = 2048;
+constexpr uint32_t kSpWindow = kWindow + kLzTile + kMaxLen;  // sources + tile + look-ahead
+constexpr uint32_t kSpMaxBucket = 192;   // a bucket this full means heavy duplication: not a sparse tile
+constexpr uint32_t kSpBudget = 1400;     // candidate tests + extension steps one thread may spend (8 positions)
+
+__global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                     const uint32_t *__restrict__ sb_first, uint32_t n,
+                                                     const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
+                                                     uint8_t *__restrict__ dense_tile) {
+  __shared__ uint32_t px[kSpWindow];
+  __shared__ uint32_t cursor[kSpBuckets];   // counts, then running insert positions (end of bucket after the scatter)
+  __shared__ uint16_t count[kSpBuckets];
+  __shared__ uint16_t items[kWindow + kLzTile];
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t s_abort;
+  constexpr uint32_t kPerSuper = kSuper / kLzTile;
+  const uint32_t tile = blockIdx.x, sb = tile / kPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  const uint32_t M = st[img].M;
+  const uint32_t a = (tile - sb_first[img] * kPerSuper) * kLzTile;
+  if (a >= M) return;
+  const uint32_t b = a + kLzTile < M ? a + kLzTile : M;
+  const uint32_t lo = a > kWindow ? a - kWindow : 0;         // first possible source
+  const uint32_t hi = b + kMaxLen - 1 < M ? b + kMaxLen - 1 : M;  // one past the last pixel an extension may read
+  const uint64_t pos0 = imgs[img].pos0;
+  const uint32_t *data = pix + pos0;
+  for (uint32_t i = tid; i < kSpBuckets; i += 256) cursor[i] = 0;
+  if (tid == 0) s_abort = 0;
+  for (uint32_t i = tid; i < hi - lo; i += 256) px[i] = data[lo + i];
+  __syncthreads();
+  const uint32_t nsrc = b - lo;  // pixels lo..b-1 can be sources
+  for (uint32_t i = tid; i < nsrc; i += 256) atomicAdd(&cursor[(px[i] * 0x9E3779B1u) >> 21], 1u);
+  __syncthreads();
+  // exclusive scan of the 2048 counts (8 per thread)
+  uint32_t c[8], sum = 0, mx = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { c[k] = cursor[tid * 8 + k]; sum += c[k]; mx = c[k] > mx ? c[k] : mx; }
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  const uint32_t incl = wave_incl_scan_u32(sum, (int)lane);
+  if (lane == 63) wsum[wave] = incl;
+  if (mx > kSpMaxBucket) s_abort = 1;
+  __syncthreads();
+  if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
+  uint32_t run = incl - sum;
+  for (uint32_t k = 0; k < wave; k++) run += wsum[k];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { cursor[tid * 8 + k] = run; count[tid * 8 + k] = (uint16_t)c[k]; run += c[k]; }
+  __syncthreads();
+  for (uint32_t i = tid; i < nsrc; i += 256) items[atomicAdd(&cursor[(px[i] * 0x9E3779B1u) >> 21], 1u)] = (uint16_t)i;
+  __syncthreads();
+  // every thread: positions a+tid, a+tid+256, ...
+  uint32_t out[kLzTile / 256];
+  uint32_t spent = 0;
+  bool over = false;
+#pragma unroll 1
+  for (uint32_t k = 0; k < kLzTile / 256; k++) {
+    const uint32_t p = a + k * 256 + tid;
+    uint32_t key = 0;
+    if (p < b && !over) {
+      const uint32_t ip = p - lo, x = px[ip];
+      const uint32_t h = (x * 0x9E3779B1u) >> 21;
+      const uint32_t end = cursor[h], beg = end - count[h];
+      const uint32_t rem = M - p < kMaxLen ? M - p : kMaxLen;
+      for (uint32_t i = beg; i < end; i++) {
+        const uint32_t iq = items[i];
+        spent++;
+        if (iq >= ip || ip - iq > kWindow || px[iq] != x) continue;
+        const uint32_t d = ip - iq;
+        const uint32_t maxl = d < rem ? d : rem;  // no overlap with the source, at most 128, inside the image
+        uint32_t l = 1;
+        while (l < maxl && px[iq + l] == px[ip + l]) l++;
+        spent += l;
+        const uint32_t kk = (l << 11) | d;  // longest, then farthest (lz77.h:68)
+        key = kk > key ? kk : key;
+      }
+      if (spent > kSpBudget) over = true;
+      if (p == M - 1) key = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
+    }
+    out[k] = key ? ((key >> 11) | ((key & 2047u) << 8)) : 0u;
+  }
+  if (over) s_abort = 1;
+  __syncthreads();
+  if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
+#pragma unroll
+  for (uint32_t k = 0; k < kLzTile / 256; k++) {
+    const uint32_t p = a + k * 256 + tid;
+    if (p < b) match[pos0 + p] = out[k];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                               const uint32_t *__restrict__ sb_first, uint32_t n,
-                                              const uint32_t *__restrict__ pix, uint32_t *__restrict__ match) {
+                                              const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
+                                              const uint8_t *__restrict__ dense_tile) {
   constexpr uint32_t kPerSuper = kSuper / kLzBlock;
   const uint32_t blk = blockIdx.x, sb = blk / kPerSuper, img = find_image(sb_first, n, sb);
   const uint32_t M = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[img].M);
@@ -329,6 +430,8 @@ __global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs,
   if (a >= M) return;
   const uint32_t b = a + kLzTile < M ? a + kLzTile : M;
   const uint64_t pos0 = imgs[img].pos0;
+  // tiles the candidate-list kernel completed are done; it flags the ones it gave up on
+  if (dense_tile && __builtin_amdgcn_readfirstlane((int)dense_tile[(pos0 + a) / kLzTile]) == 0) return;
   if (a == 0) lz77_tile<true>(pix + pos0, match + pos0, M, a, b, lane);
   else lz77_tile<false>(pix + pos0, match + pos0, M, a, b, lane);
 }
@@ -759,7 +862,8 @@ struct vp8l_encoder {
   std::mutex mu;
   // workspace (grown on demand)
   DeviceBuffer d_imgs, d_state, d_sbfirst, d_gsets, d_pix, d_match, d_flags, d_histo, d_tables, d_sx, d_entry,
-      d_unit_bits, d_unit_off;
+      d_unit_bits, d_unit_off, d_dense;
+  int match_mode = 0;  // 0 = candidate lists with exhaustive fallback, 1 = exhaustive only
   // last batch
   std::vector<EncImage> imgs;
   std::vector<EncState> states;
@@ -796,7 +900,7 @@ extern "C" void vp8l_encoder_destroy(vp8l_encoder *e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   DeviceBuffer *bufs[] = {&e->d_imgs, &e->d_state, &e->d_sbfirst, &e->d_gsets, &e->d_pix, &e->d_match, &e->d_flags,
-                          &e->d_histo, &e->d_tables, &e->d_sx, &e->d_entry, &e->d_unit_bits, &e->d_unit_off};
+                          &e->d_histo, &e->d_tables, &e->d_sx, &e->d_entry, &e->d_unit_bits, &e->d_unit_off, &e->d_dense};
   for (auto *b : bufs) b->release();
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -856,7 +960,8 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
             e->d_pix.reserve(npos * 4) && e->d_match.reserve(npos * 4) && e->d_flags.reserve(npos / 8) &&
             e->d_histo.reserve((size_t)nl * kNumCodes * kCodeStride * 4) && e->d_tables.reserve((size_t)nl * sizeof(CodeTables)) &&
             e->d_sx.reserve(sb_total * kBlockLen) && e->d_entry.reserve(sb_total) &&
-            e->d_unit_bits.reserve(nunits * 4) && e->d_unit_off.reserve(nunits * 8);
+            e->d_unit_bits.reserve(nunits * 4) && e->d_unit_off.reserve(nunits * 8) &&
+            e->d_dense.reserve(sb_total * (kSuper / kLzTile));
   if (!ok) return VP8L_ERR_NO_MEMORY;
 
   hipStream_t s = e->stream;
@@ -873,6 +978,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   auto *entry = e->d_entry.as<uint8_t>();
   auto *ubits = e->d_unit_bits.as<uint32_t>();
   auto *uoff = e->d_unit_off.as<uint64_t>();
+  auto *dense = e->d_dense.as<uint8_t>();
 
   bool h = true;
   h = h && hip_ok(hipMemcpyAsync(imgs, e->imgs.data(), nl * sizeof(EncImage), hipMemcpyHostToDevice, s), "upload images");
@@ -880,6 +986,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   h = h && hip_ok(hipMemsetAsync(st, 0, nl * sizeof(EncState), s), "clear state");
   h = h && hip_ok(hipMemsetAsync(gsets, 0xff, (size_t)nl * kSetSlots * sizeof(unsigned long long), s), "clear sets");
   h = h && hip_ok(hipMemsetAsync(histo, 0, (size_t)nl * kNumCodes * kCodeStride * 4, s), "clear histograms");
+  h = h && hip_ok(hipMemsetAsync(dense, 0, sb_total * (kSuper / kLzTile), s), "clear tile flags");
   if (!h) return VP8L_ERR_HIP;
 
   const uint32_t gsb = (uint32_t)sb_total, gunits = (uint32_t)nunits;
@@ -889,7 +996,10 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   (void)hipEventRecord(e->ev[1], s);
   hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix);
   (void)hipEventRecord(e->ev[2], s);
-  hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match);
+  if (e->match_mode == 0)
+    hipLaunchKernelGGL(k_lz77_sparse, dim3(gsb * (kSuper / kLzTile)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, dense);
+  hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match,
+                     e->match_mode == 0 ? dense : (const uint8_t *)nullptr);
   (void)hipEventRecord(e->ev[3], s);
   hipLaunchKernelGGL(k_parse_exits, dim3(gsb), dim3(128), 0, s, imgs, st, sbf, nl, match, sx);
   hipLaunchKernelGGL(k_parse_chain, dim3(nl), dim3(256), 0, s, st, sbf, sx, entry);
@@ -972,6 +1082,33 @@ extern "C" long vp8l_encoder_fetch_stage(vp8l_encoder *e, size_t image, int what
 }
 
 extern "C" double vp8l_encoder_last_device_seconds(const vp8l_encoder *e) { return e ? e->last_seconds : 0.0; }
+
+extern "C" int vp8l_encoder_set_option(vp8l_encoder *e, int option, int value) {
+  if (!e) return VP8L_ERR_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lock(e->mu);
+  if (option == VP8L_OPT_MATCH_SEARCH && (value == 0 || value == 1)) { e->match_mode = value; return VP8L_OK; }
+  return VP8L_ERR_BAD_ARGUMENT;
+}
+
+extern "C" long vp8l_encoder_last_dense_tiles(vp8l_encoder *e, long *total_tiles) {
+  if (!e) return VP8L_ERR_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lock(e->mu);
+  if (e->sb_first.empty()) return 0;
+  if (!hip_ok(hipSetDevice(e->device), "hipSetDevice")) return VP8L_ERR_HIP;
+  const size_t ntiles = (size_t)e->sb_first.back() * (kSuper / kLzTile);
+  std::vector<uint8_t> f(ntiles);
+  if (!hip_ok(hipMemcpy(f.data(), e->d_dense.ptr, ntiles, hipMemcpyDeviceToHost), "fetch tile flags")) return VP8L_ERR_HIP;
+  long dense = 0, total = 0;
+  // count only tiles that hold pixels
+  for (size_t i = 0; i < e->imgs.size(); i++) {
+    if (!e->imgs[i].argb) continue;
+    const uint64_t t0 = e->imgs[i].pos0 / kLzTile, nt = ((uint64_t)e->states[i].M + kLzTile - 1) / kLzTile;
+    for (uint64_t t = 0; t < nt; t++) dense += f[t0 + t];
+    total += (long)nt;
+  }
+  if (total_tiles) *total_tiles = total;
+  return e->match_mode == 0 ? dense : total;
+}
 
 extern "C" int vp8l_encoder_last_stage_seconds(const vp8l_encoder *e, double *seconds, int cap) {
   if (!e || !seconds) return VP8L_ERR_BAD_ARGUMENT;
