@@ -158,3 +158,20 @@ def test_device_generator_matches_oracle():
 def test_medium_images_bytes_equal():
     for mode, w, h in ((3, 512, 512), (4, 512, 512), (5, 512, 512), (3, 1920, 120), (4, 777, 333)):
         check_stream(O.gen_image(mode, w, h, 12345, 200), w, h)
+
+
+def test_unit_longer_than_the_staging_window():
+    # 6144 consecutive tokens whose codes are long (symbols that are rare in every channel): more stream
+    # bits than the emit kernel's 131072-bit staging window, so a unit is written in several windows
+    rng = np.random.default_rng(77)
+    w, h = 4096, 64
+    c = rng.integers(0, 16, size=(w * h, 3)).astype(np.uint32)
+    base = np.uint32(0xFF000000) | (c[:, 0] << 16) | (c[:, 1] << 8) | c[:, 2]
+    img = base.copy()
+    rare = rng.integers(16, 256, size=(6144, 4)).astype(np.uint32)
+    img[20 * w: 20 * w + 6144] = (rare[:, 0] << 24) | (rare[:, 1] << 16) | (rare[:, 2] << 8) | rare[:, 3]
+    plain = check_stream(base, w, h)
+    got = check_stream(img, w, h)
+    assert 8 * (len(got) - len(plain)) > 6144 * 36   # the stretch costs well over 32 bits a pixel
+    dec, dw, dh = webp_amd.decode(got)
+    assert (dw, dh) == (w, h) and np.array_equal(dec, img)

@@ -89,8 +89,8 @@ VP8L_HD void prefix_decode_base(uint32_t sym, uint32_t &base, uint32_t &nbits) {
 }
 
 // lz77.cpp:38-47 / :104-112.  The reference computes in size_t, so "xsize - 8" wraps for
-// xsize < 8 and its second branch is then never taken; 64-bit unsigned here does the same.
-VP8L_HD uint32_t dist_to_code(uint32_t xsize_, uint32_t dist_) {
+// xsize < 8 and its second branch is then never taken.
+VP8L_HD uint32_t dist_xy_to_code(uint32_t xsize, uint32_t x, uint32_t y, uint32_t dist) {  // dist = y*xsize + x, x < xsize
   constexpr uint8_t lut[128] = {
       96,  73,  55,  39,  23,  13,  5,   1,   255, 255, 255, 255, 255, 255, 255, 255,
       101, 78,  58,  42,  26,  16,  8,   2,   0,   3,   9,   17,  27,  43,  59,  79,
@@ -100,12 +100,21 @@ VP8L_HD uint32_t dist_to_code(uint32_t xsize_, uint32_t dist_) {
       115, 108, 94,  76,  64,  50,  44,  40,  34,  41,  45,  51,  65,  77,  95,  109,
       118, 113, 103, 92,  80,  68,  60,  56,  54,  57,  61,  69,  81,  93,  104, 114,
       119, 116, 111, 106, 97,  88,  84,  74,  72,  75,  85,  89,  98,  107, 112, 117};
-  const uint64_t xsize = xsize_, dist = dist_;
-  const uint64_t y = dist / xsize, x = dist - y * xsize;
   if (x <= 8 && y < 8) return (uint32_t)lut[y * 16 + 8 - x] + 1;
-  if (x > xsize - 8 && y < 7) return (uint32_t)lut[(y + 1) * 16 + 8 + (xsize - x)] + 1;
-  return (uint32_t)dist + 120;
+  if (xsize >= 8 && x > xsize - 8 && y < 7) return (uint32_t)lut[(y + 1) * 16 + 8 + (xsize - x)] + 1;  // never for xsize < 8 (size_t wrap)
+  return dist + 120;
 }
+VP8L_HD uint32_t dist_to_code(uint32_t xsize, uint32_t dist) {
+  const uint32_t y = dist / xsize;
+  return dist_xy_to_code(xsize, dist - y * xsize, y, dist);
+}
+// The same with the division done by a multiplication: xinv = ceil(2^32 / xsize) for xsize >= 2.
+// Exact for dist * xsize < 2^32 (here dist <= 1024, xsize <= 16384).
+VP8L_HD uint32_t dist_to_code_inv(uint32_t xsize, uint32_t xinv, uint32_t dist) {
+  const uint32_t y = xsize == 1 ? dist : (uint32_t)(((uint64_t)dist * xinv) >> 32);
+  return dist_xy_to_code(xsize, dist - y * xsize, y, dist);
+}
+VP8L_HD uint32_t dist_inverse(uint32_t xsize) { return xsize >= 2 ? (uint32_t)((0x100000000ull + xsize - 1) / xsize) : 0u; }
 
 // lz77.cpp:20-35 / :59-70 in uint32 arithmetic like the reference (a negative dx with a small
 // dy*xsize wraps to a huge distance; it is not clamped to 1).  The table is the inverse of the

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_palette_finalize(const EncImage *__rest
   __syncthreads();
   const bool none = s.pal_overflow || s.pal_count > kMaxPalette || s.pal_count == 0;
   if (none) {
-    if (tid == 0) { s.ncolors = 0; s.bits = 0; s.xsize = im.w; s.M = im.w * im.h; }
+    if (tid == 0) { s.ncolors = 0; s.bits = 0; s.xsize = im.w; s.M = im.w * im.h; s.xinv = dist_inverse(im.w); }
     return;
   }
   const unsigned long long *gset = gsets + (size_t)img * kSetSlots;
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void k_palette_finalize(const EncImage *__rest
     s.bits = bits;
     s.xsize = (im.w + (1u << bits) - 1) >> bits;
     s.M = s.xsize * im.h;
+    s.xinv = dist_inverse(s.xsize);
   }
 }
 
@@ -256,7 +257,8 @@ __device__ __forceinline__ uint32_t lz77_chunk(uint32_t (&mis)[16], const uint32
 // a, b, M are wave-uniform (scalar registers).
 template <bool HEAD>
 __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uint32_t *__restrict__ match, const uint32_t M,
-                                          const uint32_t a, const uint32_t b, const int lane) {
+                                          const uint32_t a, const uint32_t b, const int lane, const uint32_t xsize,
+                                          const uint32_t xinv) {
   const uint32_t qs = (b + 127 < M - 1) ? b + 127 : M - 1;
   const int ctop = (int)(qs >> 4);
   const int cbot = (int)(a >> 4);
@@ -304,7 +306,7 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
           uint32_t len = (res >> 10) - (16u - (uint32_t)lane);
           const uint32_t dist = (res & 1023u) + 1u;
           if (p == M - 1) len = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
-          match[p] = len ? (len | (dist << 8)) : 0u;
+          match[p] = len ? (len | (dist << 8) | (dist_to_code_inv(xsize, xinv, dist) << 19)) : 0u;
         }
       }
     } else {
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
   __shared__ uint32_t s_abort;
   constexpr uint32_t kPerSuper = kSuper / kLzTile;
   const uint32_t tile = blockIdx.x, sb = tile / kPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
-  const uint32_t M = st[img].M;
+  const uint32_t M = st[img].M, xsize = st[img].xsize, xinv = st[img].xinv;
   const uint32_t a = (tile - sb_first[img] * kPerSuper) * kLzTile;
   if (a >= M) return;
   const uint32_t b = a + kLzTile < M ? a + kLzTile : M;
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
       if (spent > kSpBudget) over = true;
       if (p == M - 1) key = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
     }
-    out[k] = key ? ((key >> 11) | ((key & 2047u) << 8)) : 0u;
+    out[k] = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_to_code_inv(xsize, xinv, key & 2047u) << 19)) : 0u;
   }
   if (over) s_abort = 1;
   __syncthreads();
@@ -432,8 +434,9 @@ __global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs,
   const uint64_t pos0 = imgs[img].pos0;
   // tiles the candidate-list kernel completed are done; it flags the ones it gave up on
   if (dense_tile && __builtin_amdgcn_readfirstlane((int)dense_tile[(pos0 + a) / kLzTile]) == 0) return;
-  if (a == 0) lz77_tile<true>(pix + pos0, match + pos0, M, a, b, lane);
-  else lz77_tile<false>(pix + pos0, match + pos0, M, a, b, lane);
+  const uint32_t xsize = st[img].xsize, xinv = st[img].xinv;
+  if (a == 0) lz77_tile<true>(pix + pos0, match + pos0, M, a, b, lane, xsize, xinv);
+  else lz77_tile<false>(pix + pos0, match + pos0, M, a, b, lane, xsize, xinv);
 }
 
 // =============================================================================================
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(256) void k_histogram(const EncImage *__restrict__ 
                                                    const uint32_t *__restrict__ flags, uint32_t *__restrict__ histo) {
   __shared__ uint32_t h[kNumCodes * kCodeStride];
   const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
-  const uint32_t M = st[img].M, xsize = st[img].xsize;
+  const uint32_t M = st[img].M;
   const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
   if (p0 >= M) return;
   for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) h[i] = 0;
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(256) void k_histogram(const EncImage *__restrict__ 
       uint32_t sym, nb, eb;
       prefix_encode(len, sym, nb, eb);
       atomicAdd(&h[kGreen * kCodeStride + 256 + sym], 1u);
-      prefix_encode(dist_to_code(xsize, (m >> 8) & 0x7ff), sym, nb, eb);
+      prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);  // distance code, computed with the match
       atomicAdd(&h[kDist * kCodeStride + sym], 1u);
     }
   }
@@ -623,39 +626,69 @@ __global__ __launch_bounds__(64) void k_entropy_header(const EncImage *__restric
 // =============================================================================================
 // Token bits: count per unit, scan per image, emit through an LDS staging window.
 // =============================================================================================
-struct CountPut {
-  uint32_t bits = 0;
-  __device__ __forceinline__ void operator()(uint32_t, uint32_t n) { bits += n; }
-};
-
-__device__ __forceinline__ void load_tables(CodeTables &dst, const CodeTables *__restrict__ src, uint32_t tid) {
-  const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
-  uint32_t *d = reinterpret_cast<uint32_t *>(&dst);
-  for (uint32_t i = tid; i < sizeof(CodeTables) / 4; i += 256) d[i] = s[i];
+// A match word holds length (bits 0-7), distance (8-18) and the distance code (19-29).
+// Bits of one token with the code lengths alone (vp8l.h:545-583).
+__device__ __forceinline__ uint32_t token_bit_count(const uint8_t *lens, const bool *wr, uint32_t pixel, uint32_t m) {
+  const uint32_t len = m & 0xff;
+  if (len == 0) {
+    uint32_t bits = 0;
+    if (wr[kGreen]) bits += lens[kGreen * kCodeStride + ((pixel >> 8) & 0xff)];
+    if (wr[kRed]) bits += lens[kRed * kCodeStride + ((pixel >> 16) & 0xff)];
+    if (wr[kBlue]) bits += lens[kBlue * kCodeStride + (pixel & 0xff)];
+    if (wr[kAlpha]) bits += lens[kAlpha * kCodeStride + (pixel >> 24)];
+    return bits;
+  }
+  uint32_t sym, nb, eb, bits;
+  prefix_encode(len, sym, nb, eb);
+  bits = lens[kGreen * kCodeStride + 256 + sym] + nb;  // always written (vp8l.h:570)
+  prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);
+  bits += nb;
+  if (wr[kDist]) bits += lens[kDist * kCodeStride + sym];
+  return bits;
 }
 
+// sum over the 16 lanes of a row, valid in the row's last lane
+__device__ __forceinline__ uint32_t row16_sum_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+  return v;
+}
+
+// Token bits per group of 16 positions (what one k_emit thread writes) and per unit.
 __global__ __launch_bounds__(256) void k_bitcount(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                   const uint32_t *__restrict__ sb_first, uint32_t n,
                                                   const uint32_t *__restrict__ pix, const uint32_t *__restrict__ match,
                                                   const uint32_t *__restrict__ flags, const CodeTables *__restrict__ tables,
-                                                  uint32_t *__restrict__ unit_bits) {
-  __shared__ CodeTables tab;
+                                                  uint16_t *__restrict__ group_bits, uint32_t *__restrict__ unit_bits) {
+  __shared__ __attribute__((aligned(16))) uint8_t lens[kNumCodes * kCodeStride];
   __shared__ uint32_t wsum[4];
   const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
-  const uint32_t M = st[img].M, xsize = st[img].xsize;
+  const uint32_t M = st[img].M;
   const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
   if (p0 >= M) return;
-  load_tables(tab, &tables[img], tid);
+  const CodeTables *T = &tables[img];
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride / 4; i += 256)
+    reinterpret_cast<uint32_t *>(lens)[i] = reinterpret_cast<const uint32_t *>(T->len)[i];
+  bool wr[kNumCodes];
+#pragma unroll
+  for (int c = 0; c < kNumCodes; c++) wr[c] = T->used[c] > 1;
   __syncthreads();
   const uint64_t pos0 = imgs[img].pos0;
-  CountPut cnt;
+  uint32_t total = 0;
   for (uint32_t k = 0; k < kUnit / 256; k++) {
     const uint32_t p = p0 + k * 256 + tid;
-    if (p >= M || !flag_at(flags, pos0 + p)) continue;
-    const uint32_t m = match[pos0 + p], len = m & 0xff;
-    emit_token(cnt, tab, len ? 0u : pix[pos0 + p], len, (m >> 8) & 0x7ff, xsize);
+    uint32_t bits = 0;
+    if (p < M && flag_at(flags, pos0 + p)) {
+      const uint32_t m = match[pos0 + p];
+      bits = token_bit_count(lens, wr, (m & 0xff) ? 0u : pix[pos0 + p], m);
+    }
+    total += bits;
+    const uint32_t g = row16_sum_u32(bits);
+    if ((tid & 15) == 15 && (p - 15) < M) group_bits[(pos0 + p) >> 4] = (uint16_t)g;
   }
-  const uint32_t s = wave_sum_u32(cnt.bits);
+  const uint32_t s = wave_sum_u32(total);
   if ((tid & 63) == 0) wsum[tid >> 6] = s;
   __syncthreads();
   if (tid == 0) unit_bits[unit] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
@@ -702,6 +735,7 @@ __global__ __launch_bounds__(256) void k_scan(const EncImage *__restrict__ imgs,
 
 constexpr uint32_t kWinWords = 4096;  // LDS staging window: 16 KiB = 131072 stream bits
 
+// Writer for bits that may fall partly outside the window: clips and ORs (any thread, any order).
 struct StagePut {
   uint32_t *stage;
   long long rel;  // bit position relative to the window start (may be negative / beyond)
@@ -720,72 +754,124 @@ struct StagePut {
     const uint32_t hi = (uint32_t)(val >> 32);
     if (hi) atomicOr(&stage[w + 1], hi);
   }
+  __device__ __forceinline__ void finish() {}
 };
+
+// Writer for a thread whose whole bit run lies inside the window.  A thread's tokens are one
+// contiguous run of bits: words the run covers completely are plain stores, only its first and
+// last (partial) words are shared with the neighbouring threads and are ORed.
+struct RunPut {
+  uint32_t *stage;
+  uint32_t w, fill;
+  unsigned long long acc;
+  bool first;
+  __device__ __forceinline__ RunPut(uint32_t *s, uint32_t rel) : stage(s), w(rel >> 5), fill(rel & 31), acc(0), first(true) {}
+  __device__ __forceinline__ void operator()(uint32_t v, uint32_t n) {
+    acc |= (unsigned long long)v << fill;
+    fill += n;
+    if (fill >= 32) {
+      if (first) { atomicOr(&stage[w], (uint32_t)acc); first = false; } else stage[w] = (uint32_t)acc;
+      w++;
+      acc >>= 32;
+      fill -= 32;
+    }
+  }
+  __device__ __forceinline__ void finish() { if (fill) atomicOr(&stage[w], (uint32_t)acc); }
+};
+
+template <class Put>
+__device__ __forceinline__ void emit_token_packed(Put &put, const uint2 *tab, const bool *wr, uint32_t pixel, uint32_t m) {
+  const uint32_t len = m & 0xff;
+  if (len == 0) {
+    if (wr[kGreen]) { const uint2 e = tab[kGreen * kCodeStride + ((pixel >> 8) & 0xff)]; put(e.x, e.y); }
+    if (wr[kRed]) { const uint2 e = tab[kRed * kCodeStride + ((pixel >> 16) & 0xff)]; put(e.x, e.y); }
+    if (wr[kBlue]) { const uint2 e = tab[kBlue * kCodeStride + (pixel & 0xff)]; put(e.x, e.y); }
+    if (wr[kAlpha]) { const uint2 e = tab[kAlpha * kCodeStride + (pixel >> 24)]; put(e.x, e.y); }
+  } else {
+    uint32_t sym, nb, eb;
+    prefix_encode(len, sym, nb, eb);
+    { const uint2 e = tab[kGreen * kCodeStride + 256 + sym]; put(e.x, e.y); }  // always written (vp8l.h:570)
+    if (nb) put(eb, nb);
+    prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);
+    if (wr[kDist]) { const uint2 e = tab[kDist * kCodeStride + sym]; put(e.x, e.y); }
+    if (nb) put(eb, nb);
+  }
+}
+
+// The tokens of 16 consecutive positions, fetched four at a time.
+template <class Put>
+__device__ __forceinline__ void emit_group(Put &put, const uint2 *tab, const bool *wr, const uint32_t *__restrict__ px,
+                                           const uint32_t *__restrict__ mt, uint32_t fl) {
+#pragma unroll 1
+  for (int g = 0; g < 4; g++, fl >>= 4) {
+    if ((fl & 15u) == 0) continue;
+    const uint4 m4 = *reinterpret_cast<const uint4 *>(mt + 4 * g);
+    const uint4 p4 = *reinterpret_cast<const uint4 *>(px + 4 * g);
+    if (fl & 1u) emit_token_packed(put, tab, wr, p4.x, m4.x);
+    if (fl & 2u) emit_token_packed(put, tab, wr, p4.y, m4.y);
+    if (fl & 4u) emit_token_packed(put, tab, wr, p4.z, m4.z);
+    if (fl & 8u) emit_token_packed(put, tab, wr, p4.w, m4.w);
+  }
+  put.finish();
+}
 
 __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                               const uint32_t *__restrict__ sb_first, uint32_t n,
                                               const uint32_t *__restrict__ pix, const uint32_t *__restrict__ match,
                                               const uint32_t *__restrict__ flags, const CodeTables *__restrict__ tables,
-                                              const uint32_t *__restrict__ unit_bits, const uint64_t *__restrict__ unit_off,
+                                              const uint16_t *__restrict__ group_bits, const uint64_t *__restrict__ unit_off,
                                               uint8_t *__restrict__ out) {
-  __shared__ CodeTables tab;
+  __shared__ uint2 tab[kNumCodes * kCodeStride];  // (code, length)
   __shared__ uint32_t stage[kWinWords + 2];
   __shared__ uint32_t wsum[4];
   const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   if (st[img].status != 0) return;
-  const uint32_t M = st[img].M, xsize = st[img].xsize;
+  const uint32_t M = st[img].M;
   const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
   if (p0 >= M) return;
-  const uint32_t total = unit_bits[unit];
-  if (total == 0) return;
-  load_tables(tab, &tables[img], tid);
+  const CodeTables *T = &tables[img];
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) tab[i] = make_uint2(T->code[i], T->len[i]);
+  bool wr[kNumCodes];
+#pragma unroll
+  for (int c = 0; c < kNumCodes; c++) wr[c] = T->used[c] > 1;
   const EncImage im = imgs[img];
   const uint64_t pos0 = im.pos0;
-  // this thread's 16 consecutive positions
+  // this thread's 16 consecutive positions (the arrays have readable slack past M)
   const uint32_t pb = p0 + tid * 16;
-  uint32_t mt[16];
-  uint32_t fl = 0;
+  const uint32_t *mt = match + pos0 + pb, *px = pix + pos0 + pb;
+  uint32_t fl = 0, mybits = 0;
   if (pb < M) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(match + pos0 + pb);
-    const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];  // the region has readable slack past M
-    const uint32_t L[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-#pragma unroll
-    for (int i = 0; i < 16; i++) mt[i] = L[i];
     fl = (flags[(pos0 + pb) >> 5] >> ((pos0 + pb) & 31)) & 0xffffu;
     if (pb + 16 > M) fl &= (1u << (M - pb)) - 1u;
-  } else {
-#pragma unroll
-    for (int i = 0; i < 16; i++) mt[i] = 0;
+    mybits = group_bits[(pos0 + pb) >> 4];
   }
-  __syncthreads();
-  CountPut cnt;
-#pragma unroll
-  for (int i = 0; i < 16; i++)
-    if ((fl >> i) & 1u) {
-      const uint32_t len = mt[i] & 0xff;
-      emit_token(cnt, tab, len ? 0u : pix[pos0 + pb + i], len, (mt[i] >> 8) & 0x7ff, xsize);
-    }
-  const uint32_t incl = wave_incl_scan_u32(cnt.bits, (int)lane);
+  const uint32_t incl = wave_incl_scan_u32(mybits, (int)lane);
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
   uint32_t before = 0;
   for (uint32_t k = 0; k < wave; k++) before += wsum[k];
+  const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (total == 0) return;
   const uint64_t start_bit = unit_off[unit], end_bit = start_bit + total;
-  const uint64_t my_bit = start_bit + before + incl - cnt.bits;
+  const uint64_t my_bit = start_bit + before + incl - mybits;
   const uint64_t first_word = start_bit >> 5, last_word = (end_bit - 1) >> 5;
   const uint64_t nwords = last_word - first_word + 1;
   uint32_t *out32 = reinterpret_cast<uint32_t *>(out + im.out_off);
+  constexpr long long kWinBits = (long long)kWinWords * 32;
   for (uint64_t wbase = 0; wbase < nwords; wbase += kWinWords) {
     for (uint32_t i = tid; i < kWinWords + 2; i += 256) stage[i] = 0;
     __syncthreads();
-    StagePut put{stage, (long long)my_bit - (long long)((first_word + wbase) << 5)};
-#pragma unroll
-    for (int i = 0; i < 16; i++)
-      if ((fl >> i) & 1u) {
-        const uint32_t len = mt[i] & 0xff;
-        emit_token(put, tab, len ? 0u : pix[pos0 + pb + i], len, (mt[i] >> 8) & 0x7ff, xsize);
+    const long long rel = (long long)my_bit - (long long)((first_word + wbase) << 5);
+    if (mybits && rel + (long long)mybits > 0 && rel < kWinBits) {
+      if (rel >= 0 && rel + (long long)mybits <= kWinBits) {
+        RunPut put(stage, (uint32_t)rel);
+        emit_group(put, tab, wr, px, mt, fl);
+      } else {  // the run crosses a window edge
+        StagePut put{stage, rel};
+        emit_group(put, tab, wr, px, mt, fl);
       }
+    }
     __syncthreads();
     const uint64_t cntw = nwords - wbase < kWinWords ? nwords - wbase : kWinWords;
     for (uint32_t i = tid; i < cntw; i += 256) {
@@ -862,7 +948,7 @@ struct vp8l_encoder {
   std::mutex mu;
   // workspace (grown on demand)
   DeviceBuffer d_imgs, d_state, d_sbfirst, d_gsets, d_pix, d_match, d_flags, d_histo, d_tables, d_sx, d_entry,
-      d_unit_bits, d_unit_off, d_dense;
+      d_unit_bits, d_unit_off, d_dense, d_group_bits;
   int match_mode = 0;  // 0 = candidate lists with exhaustive fallback, 1 = exhaustive only
   // last batch
   std::vector<EncImage> imgs;
@@ -900,7 +986,7 @@ extern "C" void vp8l_encoder_destroy(vp8l_encoder *e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   DeviceBuffer *bufs[] = {&e->d_imgs, &e->d_state, &e->d_sbfirst, &e->d_gsets, &e->d_pix, &e->d_match, &e->d_flags,
-                          &e->d_histo, &e->d_tables, &e->d_sx, &e->d_entry, &e->d_unit_bits, &e->d_unit_off, &e->d_dense};
+                          &e->d_histo, &e->d_tables, &e->d_sx, &e->d_entry, &e->d_unit_bits, &e->d_unit_off, &e->d_dense, &e->d_group_bits};
   for (auto *b : bufs) b->release();
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -961,7 +1047,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
             e->d_histo.reserve((size_t)nl * kNumCodes * kCodeStride * 4) && e->d_tables.reserve((size_t)nl * sizeof(CodeTables)) &&
             e->d_sx.reserve(sb_total * kBlockLen) && e->d_entry.reserve(sb_total) &&
             e->d_unit_bits.reserve(nunits * 4) && e->d_unit_off.reserve(nunits * 8) &&
-            e->d_dense.reserve(sb_total * (kSuper / kLzTile));
+            e->d_dense.reserve(sb_total * (kSuper / kLzTile)) && e->d_group_bits.reserve(npos / 16 * 2);
   if (!ok) return VP8L_ERR_NO_MEMORY;
 
   hipStream_t s = e->stream;
@@ -979,6 +1065,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   auto *ubits = e->d_unit_bits.as<uint32_t>();
   auto *uoff = e->d_unit_off.as<uint64_t>();
   auto *dense = e->d_dense.as<uint8_t>();
+  auto *gbits = e->d_group_bits.as<uint16_t>();
 
   bool h = true;
   h = h && hip_ok(hipMemcpyAsync(imgs, e->imgs.data(), nl * sizeof(EncImage), hipMemcpyHostToDevice, s), "upload images");
@@ -1009,10 +1096,10 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   (void)hipEventRecord(e->ev[5], s);
   hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(64), 0, s, imgs, st, histo, tables, d_out);
   (void)hipEventRecord(e->ev[6], s);
-  hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, ubits);
+  hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, gbits, ubits);
   hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, imgs, st, sbf, ubits, uoff, d_out);
   (void)hipEventRecord(e->ev[7], s);
-  hipLaunchKernelGGL(k_emit, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, ubits, uoff, d_out);
+  hipLaunchKernelGGL(k_emit, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, gbits, uoff, d_out);
   (void)hipEventRecord(e->ev[8], s);
   if (!hip_ok(hipGetLastError(), "kernel launch")) return VP8L_ERR_HIP;
   if (!hip_ok(hipMemcpyAsync(e->states.data(), st, nl * sizeof(EncState), hipMemcpyDeviceToHost, s), "download state")) return VP8L_ERR_HIP;
