@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Per-stage device times of the encoder for one kind of synthetic content (development aid).
+
+usage: stage_probe.py MODE [BATCH] [W] [H] [--exhaustive]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import webp_amd
+
+mode = int(sys.argv[1]); batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+w = int(sys.argv[3]) if len(sys.argv) > 3 else 3840; h = int(sys.argv[4]) if len(sys.argv) > 4 else 2160
+webp_amd.init()
+d_in = torch.empty((batch, w * h), dtype=torch.int32, device="cuda")
+for k in range(batch):
+    webp_amd.generate_device(mode, w, h, 12345 + k, 200, d_in[k].data_ptr())
+enc = webp_amd.Encoder()
+if "--exhaustive" in sys.argv:
+    enc.set_exhaustive_search(True)
+cap = enc.bound(w, h)
+d_out = torch.empty(batch * cap, dtype=torch.uint8, device="cuda")
+ptrs = [d_in[k].data_ptr() for k in range(batch)]
+for it in range(3):
+    off, lens, st = enc.encode_device(ptrs, [w] * batch, [h] * batch, d_out.data_ptr(), d_out.numel())
+assert (st == 0).all()
+ss = enc.last_stage_seconds()
+mp = batch * w * h / 1e6
+print("mode %d batch %d %dx%d: %.1f MP/s, bpp %.2f, dense tiles %s" % (mode, batch, w, h, mp / enc.last_device_seconds(), 8.0 * lens.sum() / (batch * w * h), enc.last_dense_tiles()))
+print("  " + "  ".join("%s %.2f" % (k, 1e3 * v) for k, v in ss.items()) + "  (ms)")
+print("  ns/px: " + "  ".join("%s %.3f" % (k, 1e9 * v / (mp * 1e6)) for k, v in ss.items()))

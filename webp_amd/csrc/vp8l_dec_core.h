@@ -27,8 +27,13 @@ struct BitSrc {
   const uint8_t *data;
   uint64_t len, bytepos, buf;
   uint32_t cnt;
-  VP8L_HD void init(const uint8_t *d, uint64_t l) { data = d; len = l; bytepos = 0; buf = 0; cnt = 0; }
+  // Optional copy of the stream bytes [win_lo, win_hi) as little-endian words (the device decoder keeps
+  // one in LDS; bytes past `len` are zero in it).  bytepos, win_lo and win_hi are multiples of 4.
+  const uint32_t *win;
+  uint64_t win_lo, win_hi;
+  VP8L_HD void init(const uint8_t *d, uint64_t l) { data = d; len = l; bytepos = 0; buf = 0; cnt = 0; win = nullptr; win_lo = win_hi = 0; }
   VP8L_HD uint32_t load32(uint64_t pos) const {
+    if (pos >= win_lo && pos + 4 <= win_hi) return win[(pos - win_lo) >> 2];
     uint32_t x = 0;
     if (pos + 4 <= len) {
       x = (uint32_t)data[pos] | ((uint32_t)data[pos + 1] << 8) | ((uint32_t)data[pos + 2] << 16) | ((uint32_t)data[pos + 3] << 24);
@@ -56,8 +61,9 @@ struct BitSrc {
 // reaches is the canonical-code symbol, so a table gives the same result: codes of up to
 // kLutBits bits resolve in one lookup, longer ones by the per-length counts.
 constexpr int kLutBits = 8;
+constexpr uint16_t kLongCode = 0xffff;
 struct HuffTable {
-  uint16_t lut[1 << kLutBits];  // (symbol << 4) | length, 0 = longer than kLutBits
+  uint16_t lut[1 << kLutBits];  // (symbol << 4) | length; kLongCode = longer than kLutBits; a one-leaf code has length 0
   uint16_t count[kSaneCodeLen + 1];
   uint16_t single;              // the symbol of a one-leaf code (it consumes no bits), else 0xffff
   uint16_t maxlen;
@@ -100,7 +106,11 @@ VP8L_HD int build_table(HuffTable &t, uint16_t *sorted, const uint8_t *lengths, 
   t.single = 0xffff;
   t.maxlen = (uint16_t)maxl;
   if (used == 0) return kErrInvalidHuffman;
-  if (used == 1) { t.single = (uint16_t)last; return kOk; }
+  if (used == 1) {
+    t.single = (uint16_t)last;
+    for (int i = 0; i < (1 << kLutBits); i++) t.lut[i] = (uint16_t)(last << 4);
+    return kOk;
+  }
   uint64_t kraft = 0;
   for (int l = 1; l <= maxl; l++) kraft += (uint64_t)t.count[l] << (32 - l);
   if (kraft != (1ull << 32)) return kErrInvalidHuffman;
@@ -112,7 +122,7 @@ VP8L_HD int build_table(HuffTable &t, uint16_t *sorted, const uint8_t *lengths, 
     s.next[l] = code;
     s.off[l + 1] = (uint16_t)(s.off[l] + t.count[l]);
   }
-  for (int i = 0; i < (1 << kLutBits); i++) t.lut[i] = 0;
+  for (int i = 0; i < (1 << kLutBits); i++) t.lut[i] = kLongCode;
   for (int i = 0; i < n; i++) {
     const int l = lengths[i];
     if (!l) continue;
@@ -131,7 +141,12 @@ VP8L_HD int build_simple(HuffTable &t, uint16_t *sorted, int nsym, uint32_t s0, 
   if ((int)s0 >= alphabet || (nsym == 2 && (int)s1 >= alphabet)) return kErrInvalidHuffman;
   for (int l = 0; l <= kSaneCodeLen; l++) t.count[l] = 0;
   t.single = 0xffff;
-  if (nsym == 1) { t.single = (uint16_t)s0; t.maxlen = 0; return kOk; }
+  if (nsym == 1) {
+    t.single = (uint16_t)s0;
+    t.maxlen = 0;
+    for (int i = 0; i < (1 << kLutBits); i++) t.lut[i] = (uint16_t)(s0 << 4);
+    return kOk;
+  }
   t.maxlen = 1;
   t.count[1] = 2;
   sorted[0] = (uint16_t)s0;
@@ -141,10 +156,9 @@ VP8L_HD int build_simple(HuffTable &t, uint16_t *sorted, int nsym, uint32_t s0, 
 }
 
 VP8L_HD uint32_t read_sym(BitSrc &br, const HuffTable &t, const uint16_t *sorted) {
-  if (t.single != 0xffff) return t.single;
   const uint32_t bits = br.peek32();
   const uint32_t e = t.lut[bits & ((1u << kLutBits) - 1u)];
-  if (e) { br.skip(e & 15u); return e >> 4; }
+  if (e != kLongCode) { br.skip(e & 15u); return e >> 4; }  // length 0: the symbol of a one-leaf code, no bits read
   uint32_t code = 0, first = 0, index = 0;
   for (int l = 1; l <= (int)t.maxlen; l++) {
     code |= (bits >> (l - 1)) & 1u;
@@ -159,7 +173,7 @@ VP8L_HD uint32_t read_sym(BitSrc &br, const HuffTable &t, const uint16_t *sorted
 }
 
 // ---- state machine ---------------------------------------------------------------------------
-enum : uint32_t { kEvDone = 0, kEvCopy = 1 };
+enum : uint32_t { kEvDone = 0, kEvCopy = 1, kEvRefill = 2 };
 enum : uint32_t {
   kPhStart = 0, kPhXform, kPhImgBegin, kPhPixels, kPhAfterCopy, kPhPaletteFix, kPhMain, kPhMetaDone,
   kPhGroups, kPhDone
@@ -199,16 +213,36 @@ struct DecState {
   uint32_t copy_dist, copy_len;
   int32_t status;
   uint32_t need_groups;
+  // stream window kept by the driver (see DecAccel); win_final: it reaches the end of the stream
+  uint64_t win_lo, win_hi;
+  uint32_t win_final;
+  uint32_t *cache;        // 1 << kMaxCacheBits entries
   // scratch
   TableScratch ts;
   HuffTable cl;
   uint16_t cl_sorted[kNumClSyms];
   uint8_t lengths[kMaxAlphabet];
-  uint32_t cache[1u << kMaxCacheBits];
 };
 
+// What the device driver adds around the machine; all null on the host.
+//   win   copy of win_bytes stream bytes from st.win_lo on, refilled by the driver on kEvRefill
+//   ring  the last ring_mask+1 pixels of the coded image being read (index = position & ring_mask):
+//         short back references are resolved from it without leaving the machine
+//   g0    st.groups1, for images with one Huffman group
+struct DecAccel {
+  const uint32_t *win = nullptr;
+  uint32_t win_bytes = 0;
+  uint32_t *ring = nullptr;
+  uint32_t ring_mask = 0;
+  const GroupTables *g0 = nullptr;
+};
+constexpr uint32_t kInlineCopyMax = 16;   // longer copies go to the driver (kEvCopy)
+constexpr uint32_t kWinPixelSlack = 64;   // bytes one token can need at most, with room to spare
+constexpr uint32_t kWinPhaseSlack = 1024;
+
 VP8L_HD void dec_init(DecState &st, const uint8_t *data, uint64_t len, uint32_t *out, uint32_t *aux, uint64_t aux_cap,
-                      GroupTables *groups1, GroupTables *groups_multi, uint32_t multi_cap) {
+                      GroupTables *groups1, GroupTables *groups_multi, uint32_t multi_cap, uint32_t *cache) {
+  st.cache = cache; st.win_lo = st.win_hi = 0; st.win_final = 0;
   st.data = data; st.len = len; st.out = out; st.aux = aux; st.aux_cap = aux_cap;
   st.groups = groups1; st.groups1 = groups1; st.groups_multi = groups_multi; st.multi_cap = multi_cap;
   st.bytepos = 0; st.buf = 0; st.cnt = 0;
@@ -300,13 +334,82 @@ VP8L_HD void begin_sub_image(DecState &st, uint32_t *dst, uint32_t xsize, uint32
   st.dst = dst; st.xsize = xsize; st.ysize = ysize; st.after = after; st.phase = kPhImgBegin;
 }
 
-// Runs the machine until it needs the wave (kEvCopy) or finishes (kEvDone; st.status says how).
-VP8L_HD uint32_t dec_step(DecState &st) {
+// The pixels of one coded image (ReadLZ77CodedImage vp8l.h:263-328) from st.fill on.
+enum : uint32_t { kPxFinished = 0, kPxCopy, kPxRefill, kPxFail };
+template <bool kOneGroup>
+VP8L_HD uint32_t decode_pixels(DecState &st, BitSrc &br, const DecAccel &acc) {
+  uint64_t fill = st.fill;
+  const uint64_t total = st.total;
+  uint32_t x = st.x, y = st.y;
+  const uint32_t xsize = st.xsize, cb = st.cache_bits;
+  uint32_t *dst = st.dst;
+  uint32_t *cache = st.cache;
+  uint32_t *ring = acc.ring;
+  const uint32_t rmask = acc.ring_mask;
+  const bool refillable = acc.win != nullptr && !st.win_final;
+  const GroupTables *g = acc.g0 ? acc.g0 : st.groups;
+  const GroupTables *groups = st.groups;
+  const uint32_t *meta = st.meta;
+  const uint32_t meta_bits = st.meta_bits, meta_xsize = st.meta_xsize;
+  uint32_t rc = kPxFinished;
+  while (fill < total) {
+    if (refillable && br.bytepos + kWinPixelSlack > br.win_hi) { rc = kPxRefill; break; }
+    if (!kOneGroup) g = &groups[meta[(y >> meta_bits) * meta_xsize + (x >> meta_bits)]];
+    const uint32_t S = read_sym(br, g->t[kGreen], g->sorted);
+    uint32_t px;
+    if (S < 256) {
+      const uint32_t r = read_sym(br, g->t[kRed], g->sorted);
+      const uint32_t b = read_sym(br, g->t[kBlue], g->sorted);
+      const uint32_t a = read_sym(br, g->t[kAlpha], g->sorted);
+      px = (a << 24) + (r << 16) + (S << 8) + b;
+    } else if (S < 280) {
+      uint32_t base, nb;
+      prefix_decode_base(S - 256, base, nb);
+      const uint32_t length = base + br.get(nb);
+      prefix_decode_base(read_sym(br, g->t[kDist], g->sorted), base, nb);
+      const uint32_t dcode = base + br.get(nb);
+      const uint32_t dist = code_to_dist(xsize, dcode);
+      // The reference copies without checking (vp8l.h:298-300); a reference before the start
+      // or past the end of the image is reported instead of reading/writing out of bounds.
+      if (dist > fill || fill + length > total) { st.status = kErrInvalidVp8l; rc = kPxFail; break; }
+      if (ring && length <= kInlineCopyMax && dist <= rmask + 1) {
+        for (uint32_t i = 0; i < length; i++) {  // in order: an overlapping reference repeats its own output
+          const uint32_t v = ring[(uint32_t)(fill - dist) & rmask];
+          ring[(uint32_t)fill & rmask] = v;
+          dst[fill++] = v;
+          if (cb) cache[cache_key(v, cb)] = v;
+        }
+        x += length;
+        while (x >= xsize) { x -= xsize; y++; }
+        continue;
+      }
+      st.copy_pos = fill; st.copy_dist = dist; st.copy_len = length;
+      rc = kPxCopy;
+      break;
+    } else {
+      px = cache[S - 280];
+    }
+    if (ring) ring[(uint32_t)fill & rmask] = px;
+    dst[fill++] = px;
+    // The reference inserts lazily (vp8l.h:286-288,308-310,315-324) but always in pixel order and
+    // always before the next lookup, which is what inserting every pixel at once gives.
+    if (cb) cache[cache_key(px, cb)] = px;
+    if (++x >= xsize) { x = 0; y++; }
+  }
+  st.fill = fill; st.x = x; st.y = y;
+  return rc;
+}
+
+// Runs the machine until it needs its driver (kEvCopy: a back reference to perform; kEvRefill: move
+// the stream window to st.bytepos) or finishes (kEvDone; st.status says how).
+VP8L_HD uint32_t dec_step(DecState &st, const DecAccel &acc = DecAccel()) {
   BitSrc br;
   br.data = st.data; br.len = st.len; br.bytepos = st.bytepos; br.buf = st.buf; br.cnt = st.cnt;
+  br.win = acc.win; br.win_lo = st.win_lo; br.win_hi = acc.win ? st.win_hi : 0;
 #define VP8L_SAVE_BR() do { st.bytepos = br.bytepos; st.buf = br.buf; st.cnt = br.cnt; } while (0)
 #define VP8L_FAIL(code) do { st.status = (code); st.phase = kPhDone; VP8L_SAVE_BR(); return kEvDone; } while (0)
   for (;;) {
+    if (acc.win && !st.win_final && st.phase != kPhDone && br.bytepos + kWinPhaseSlack > br.win_hi) { VP8L_SAVE_BR(); return kEvRefill; }
     switch (st.phase) {
       case kPhStart: {  // ReadInfo vp8l.h:83-94
         (void)br.get(32);
@@ -361,46 +464,11 @@ VP8L_HD uint32_t dec_step(DecState &st) {
         st.phase = kPhPixels;
         break;
       }
-      case kPhPixels: {  // ReadLZ77CodedImage vp8l.h:263-328
-        uint64_t fill = st.fill;
-        const uint64_t total = st.total;
-        uint32_t x = st.x, y = st.y;
-        const uint32_t xsize = st.xsize, cb = st.cache_bits;
-        uint32_t *dst = st.dst;
-        bool copy = false;
-        while (fill < total) {
-          const GroupTables &g = st.groups[st.ngroups == 1 ? 0u : st.meta[(y >> st.meta_bits) * st.meta_xsize + (x >> st.meta_bits)]];
-          const uint32_t S = read_sym(br, g.t[kGreen], g.sorted);
-          uint32_t px;
-          if (S < 256) {
-            const uint32_t r = read_sym(br, g.t[kRed], g.sorted);
-            const uint32_t b = read_sym(br, g.t[kBlue], g.sorted);
-            const uint32_t a = read_sym(br, g.t[kAlpha], g.sorted);
-            px = (a << 24) + (r << 16) + (S << 8) + b;
-          } else if (S < 280) {
-            uint32_t base, nb;
-            prefix_decode_base(S - 256, base, nb);
-            const uint32_t length = base + br.get(nb);
-            prefix_decode_base(read_sym(br, g.t[kDist], g.sorted), base, nb);
-            const uint32_t dcode = base + br.get(nb);
-            const uint32_t dist = code_to_dist(xsize, dcode);
-            // The reference copies without checking (vp8l.h:298-300); a reference before the start
-            // or past the end of the image is reported instead of reading/writing out of bounds.
-            if (dist > fill || fill + length > total) VP8L_FAIL(kErrInvalidVp8l);
-            st.copy_pos = fill; st.copy_dist = dist; st.copy_len = length;
-            copy = true;
-            break;
-          } else {
-            px = st.cache[S - 280];
-          }
-          dst[fill++] = px;
-          // The reference inserts lazily (vp8l.h:286-288,308-310,315-324) but always in pixel order and
-          // always before the next lookup, which is what inserting every pixel at once gives.
-          if (cb) st.cache[cache_key(px, cb)] = px;
-          if (++x >= xsize) { x = 0; y++; }
-        }
-        st.fill = fill; st.x = x; st.y = y;
-        if (copy) { st.phase = kPhAfterCopy; VP8L_SAVE_BR(); return kEvCopy; }
+      case kPhPixels: {
+        const uint32_t rc = st.ngroups == 1 ? decode_pixels<true>(st, br, acc) : decode_pixels<false>(st, br, acc);
+        if (rc == kPxFail) { st.phase = kPhDone; VP8L_SAVE_BR(); return kEvDone; }
+        if (rc == kPxCopy) { st.phase = kPhAfterCopy; VP8L_SAVE_BR(); return kEvCopy; }
+        if (rc == kPxRefill) { VP8L_SAVE_BR(); return kEvRefill; }
         st.phase = st.after;
         break;
       }
@@ -561,10 +629,11 @@ inline int host_decode(const uint8_t *data, size_t len, uint32_t *argb, size_t c
   uint32_t *aux = new uint32_t[aux_cap];
   uint32_t gcap = 64;
   DecState *st = new DecState;
+  uint32_t *cache = new uint32_t[1u << kMaxCacheBits];
   int status;
   for (;;) {
     GroupTables *groups = new GroupTables[gcap + 1];
-    dec_init(*st, data, len, argb, aux, aux_cap, groups, groups + 1, gcap);
+    dec_init(*st, data, len, argb, aux, aux_cap, groups, groups + 1, gcap, cache);
     st->w = w; st->h = h;
     while (dec_step(*st) == kEvCopy)
       for (uint32_t i = 0; i < st->copy_len; i++) st->dst[st->copy_pos + i] = st->dst[st->copy_pos + i - st->copy_dist];
@@ -617,6 +686,7 @@ inline int host_decode(const uint8_t *data, size_t len, uint32_t *argb, size_t c
   *w_out = w;
   *h_out = h;
   delete st;
+  delete[] cache;
   delete[] aux;
   return status;
 }

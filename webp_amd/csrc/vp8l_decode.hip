@@ -28,6 +28,7 @@ struct DecImage {  // host-written
   uint64_t aux_cap;
   uint32_t *scratch;      // copy of the bundled indices for the colour-indexing inverse
   GroupTables *groups;    // tables for streams with more than one Huffman group
+  uint32_t *cache;        // colour cache, 2048 entries
   uint32_t group_cap;
   uint32_t pad;
 };
@@ -40,31 +41,60 @@ struct DecResult {  // device-written
   XformRec xf[4];
 };
 
+constexpr uint32_t kRingPixels = 2048;   // recent output kept in LDS for short back references
+constexpr uint32_t kStreamWindow = 2048;  // bytes of the stream kept in LDS
+
 __global__ __launch_bounds__(64) void k_decode_entropy(const DecImage *__restrict__ imgs, DecResult *__restrict__ res) {
   __shared__ DecState st;
   __shared__ GroupTables g0;
+  __shared__ uint32_t ring[kRingPixels];
+  __shared__ uint32_t win[kStreamWindow / 4];
   const uint32_t img = blockIdx.x, lane = threadIdx.x;
   const DecImage im = imgs[img];
+  DecAccel acc;
+  acc.win = win;
+  acc.win_bytes = kStreamWindow;
+  acc.ring = ring;
+  acc.ring_mask = kRingPixels - 1;
+  acc.g0 = &g0;
   if (lane == 0) {
-    dec_init(st, im.data, im.len, im.out, im.aux, im.aux_cap, &g0, im.groups, im.group_cap);
+    dec_init(st, im.data, im.len, im.out, im.aux, im.aux_cap, &g0, im.groups, im.group_cap, im.cache);
     st.w = im.w;
     st.h = im.h;
   }
   __syncthreads();
   for (;;) {
     uint32_t ev = kEvDone;
-    if (lane == 0) ev = dec_step(st);
+    if (lane == 0) ev = dec_step(st, acc);
     ev = (uint32_t)__shfl((int)ev, 0, 64);
-    if (ev != kEvCopy) break;
-    __syncthreads();  // lane 0's copy request (LDS) and pixel stores (HBM) before the wave's loads
-    __threadfence_block();
-    uint32_t *dst = st.dst;
-    const uint64_t pos = st.copy_pos;
-    const uint32_t dist = st.copy_dist, len = st.copy_len;
-    // pixel i of the copy equals pixel (i mod dist) of the source window: correct for overlapping
-    // references too, and every source is already final
-    for (uint32_t i = lane; i < len; i += 64) dst[pos + i] = dst[pos - dist + (dist >= len ? i : i % dist)];
-    __threadfence_block();
+    if (ev == kEvDone) break;
+    __syncthreads();  // lane 0's request (LDS) and pixel stores (HBM) before the wave acts on them
+    if (ev == kEvRefill) {
+      // the stream is 4-byte aligned (checked by the host); bytes past its end read as zero
+      const uint64_t lo = st.bytepos;
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(im.data);
+      for (uint32_t i = lane; i < kStreamWindow / 4; i += 64) {
+        const uint64_t pos = lo + 4ull * i;
+        uint32_t v = 0;
+        if (pos + 4 <= im.len) v = src[pos >> 2];
+        else for (uint32_t k = 0; k < 4; k++) if (pos + k < im.len) v |= (uint32_t)im.data[pos + k] << (8 * k);
+        win[i] = v;
+      }
+      if (lane == 0) { st.win_lo = lo; st.win_hi = lo + kStreamWindow; st.win_final = lo + kStreamWindow >= im.len; }
+    } else {
+      __threadfence_block();
+      uint32_t *dst = st.dst;
+      const uint64_t pos = st.copy_pos;
+      const uint32_t dist = st.copy_dist, len = st.copy_len;
+      // pixel i of the copy equals pixel (i mod dist) of the source window: correct for overlapping
+      // references too, and every source is already final (in HBM: lane 0 stores every pixel there too)
+      for (uint32_t i = lane; i < len; i += 64) {
+        const uint32_t v = dst[pos - dist + (dist >= len ? i : i % dist)];
+        dst[pos + i] = v;
+        if (i + kRingPixels >= len) ring[(uint32_t)(pos + i) & (kRingPixels - 1)] = v;
+      }
+      __threadfence_block();
+    }
     __syncthreads();
   }
   if (lane == 0) {
@@ -200,7 +230,7 @@ struct vp8l_decoder {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
-  DeviceBuffer d_imgs, d_res, d_sbfirst, d_aux, d_scratch, d_groups;
+  DeviceBuffer d_imgs, d_res, d_sbfirst, d_aux, d_scratch, d_groups, d_cache;
   double last_seconds = 0;
 };
 
@@ -226,7 +256,7 @@ extern "C" void vp8l_decoder_destroy(vp8l_decoder *d) {
   if (d->stream) (void)hipStreamSynchronize(d->stream);
   if (d->ev0) (void)hipEventDestroy(d->ev0);
   if (d->ev1) (void)hipEventDestroy(d->ev1);
-  DeviceBuffer *bufs[] = {&d->d_imgs, &d->d_res, &d->d_sbfirst, &d->d_aux, &d->d_scratch, &d->d_groups};
+  DeviceBuffer *bufs[] = {&d->d_imgs, &d->d_res, &d->d_sbfirst, &d->d_aux, &d->d_scratch, &d->d_groups, &d->d_cache};
   for (auto *b : bufs) b->release();
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
@@ -264,12 +294,14 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
   const bool ok = d->d_imgs.reserve(m * sizeof(DecImage)) && d->d_res.reserve(m * sizeof(DecResult)) &&
                   d->d_sbfirst.reserve((m + 1) * 4) && d->d_aux.reserve(aux_total * 4) &&
                   d->d_scratch.reserve(scratch_total * 4) &&
-                  d->d_groups.reserve((size_t)m * group_cap * sizeof(GroupTables) + 16);
+                  d->d_groups.reserve((size_t)m * group_cap * sizeof(GroupTables) + 16) &&
+                  d->d_cache.reserve((size_t)m * (4u << kMaxCacheBits));
   if (!ok) return VP8L_ERR_NO_MEMORY;
   for (uint32_t k = 0; k < m; k++) {
     imgs[k].aux = d->d_aux.as<uint32_t>() + reinterpret_cast<uintptr_t>(imgs[k].aux);
     imgs[k].scratch = d->d_scratch.as<uint32_t>() + reinterpret_cast<uintptr_t>(imgs[k].scratch);
     imgs[k].groups = d->d_groups.as<GroupTables>() + (size_t)k * group_cap;
+    imgs[k].cache = d->d_cache.as<uint32_t>() + ((size_t)k << kMaxCacheBits);
   }
   hipStream_t s = d->stream;
   auto *dimgs = d->d_imgs.as<DecImage>();

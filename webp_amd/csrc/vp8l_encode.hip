@@ -321,7 +321,7 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
 
 // =============================================================================================
 // Candidate-list form of the same search, for tiles whose window holds few equal pixels (natural
-// images).  The 1024 + 2048 pixels that can be a match source for the tile are bucketed by a hash of
+// images).  The 1024 + 1024 pixels that can be a match source for a tile are bucketed by a hash of
 // the pixel value (counting sort in LDS); a position then looks only at the earlier pixels of its
 // own bucket, keeps those with the same VALUE within 1024 (exactly the distances whose first pixel
 // matches, i.e. every candidate the exhaustive search can score above zero) and extends each by
@@ -330,28 +330,33 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
 // exceeds a work budget and is handed to the exhaustive kernel (k_lz77) through `dense_tile`.
 // Both kernels produce identical results; only the time differs.
 // =============================================================================================
-constexpr uint32_t kSpBuckets = 2048;
-constexpr uint32_t kSpWindow = kWindow + kLzTile + kMaxLen;  // sources + tile + look-ahead
+constexpr uint32_t kSpTile = 1024;                   // positions per workgroup
+constexpr uint32_t kSpPosBits = 11;                  // sources of a tile: the 1024 before it and the tile itself
+constexpr uint32_t kSpSources = 1u << kSpPosBits;
+constexpr uint32_t kSpBuckets = 1u << kSpPosBits;    // top bits of the mixed pixel select the bucket ...
+constexpr uint32_t kSpTagShift = kSpPosBits;         // ... the remaining low bits are kept with the entry
+constexpr uint32_t kSpMul = 0x9E3779B1u;             // odd: x -> x * kSpMul is a bijection on 32 bits, so
+                                                     // same bucket + same tag <=> same pixel value
 constexpr uint32_t kSpMaxBucket = 192;   // a bucket this full means heavy duplication: not a sparse tile
-constexpr uint32_t kSpBudget = 1400;     // candidate tests + extension steps one thread may spend (8 positions)
+constexpr uint32_t kSpBudget = 700;      // candidate tests + extension steps one thread may spend (4 positions)
+static_assert(kSpSources == kWindow + kSpTile, "entry layout");
 
 __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                      const uint32_t *__restrict__ sb_first, uint32_t n,
                                                      const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                                      uint8_t *__restrict__ dense_tile) {
-  __shared__ uint32_t px[kSpWindow];
-  __shared__ uint32_t cursor[kSpBuckets];   // counts, then running insert positions (end of bucket after the scatter)
-  __shared__ uint16_t count[kSpBuckets];
-  __shared__ uint16_t items[kWindow + kLzTile];
+  __shared__ uint32_t px[kSpSources + kMaxLen];
+  __shared__ uint32_t cursor[kSpBuckets];  // counts, then insert positions; after the scatter cursor[h] = end of bucket h
+  __shared__ uint32_t items[kSpSources];   // (low bits of the mixed pixel) << 11 | index in px
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t s_abort;
-  constexpr uint32_t kPerSuper = kSuper / kLzTile;
+  constexpr uint32_t kPerSuper = kSuper / kSpTile;
   const uint32_t tile = blockIdx.x, sb = tile / kPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   const uint32_t M = st[img].M, xsize = st[img].xsize, xinv = st[img].xinv;
-  const uint32_t a = (tile - sb_first[img] * kPerSuper) * kLzTile;
+  const uint32_t a = (tile - sb_first[img] * kPerSuper) * kSpTile;
   if (a >= M) return;
-  const uint32_t b = a + kLzTile < M ? a + kLzTile : M;
-  const uint32_t lo = a > kWindow ? a - kWindow : 0;         // first possible source
+  const uint32_t b = a + kSpTile < M ? a + kSpTile : M;
+  const uint32_t lo = a > kWindow ? a - kWindow : 0;              // first possible source
   const uint32_t hi = b + kMaxLen - 1 < M ? b + kMaxLen - 1 : M;  // one past the last pixel an extension may read
   const uint64_t pos0 = imgs[img].pos0;
   const uint32_t *data = pix + pos0;
@@ -360,9 +365,9 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
   for (uint32_t i = tid; i < hi - lo; i += 256) px[i] = data[lo + i];
   __syncthreads();
   const uint32_t nsrc = b - lo;  // pixels lo..b-1 can be sources
-  for (uint32_t i = tid; i < nsrc; i += 256) atomicAdd(&cursor[(px[i] * 0x9E3779B1u) >> 21], 1u);
+  for (uint32_t i = tid; i < nsrc; i += 256) atomicAdd(&cursor[(px[i] * kSpMul) >> (32 - kSpPosBits)], 1u);
   __syncthreads();
-  // exclusive scan of the 2048 counts (8 per thread)
+  // exclusive scan of the bucket counts (8 per thread)
   uint32_t c[8], sum = 0, mx = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) { c[k] = cursor[tid * 8 + k]; sum += c[k]; mx = c[k] > mx ? c[k] : mx; }
@@ -375,34 +380,42 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
   uint32_t run = incl - sum;
   for (uint32_t k = 0; k < wave; k++) run += wsum[k];
 #pragma unroll
-  for (int k = 0; k < 8; k++) { cursor[tid * 8 + k] = run; count[tid * 8 + k] = (uint16_t)c[k]; run += c[k]; }
+  for (int k = 0; k < 8; k++) { cursor[tid * 8 + k] = run; run += c[k]; }
   __syncthreads();
-  for (uint32_t i = tid; i < nsrc; i += 256) items[atomicAdd(&cursor[(px[i] * 0x9E3779B1u) >> 21], 1u)] = (uint16_t)i;
+  for (uint32_t i = tid; i < nsrc; i += 256) {
+    const uint32_t mixed = px[i] * kSpMul;
+    items[atomicAdd(&cursor[mixed >> (32 - kSpPosBits)], 1u)] = (mixed << kSpTagShift) | i;
+  }
   __syncthreads();
   // every thread: positions a+tid, a+tid+256, ...
-  uint32_t out[kLzTile / 256];
+  uint32_t out[kSpTile / 256];
   uint32_t spent = 0;
   bool over = false;
 #pragma unroll 1
-  for (uint32_t k = 0; k < kLzTile / 256; k++) {
+  for (uint32_t k = 0; k < kSpTile / 256; k++) {
     const uint32_t p = a + k * 256 + tid;
     uint32_t key = 0;
     if (p < b && !over) {
-      const uint32_t ip = p - lo, x = px[ip];
-      const uint32_t h = (x * 0x9E3779B1u) >> 21;
-      const uint32_t end = cursor[h], beg = end - count[h];
+      const uint32_t ip = p - lo;
+      const uint32_t mixed = px[ip] * kSpMul, h = mixed >> (32 - kSpPosBits), tag = mixed << kSpTagShift;
+      const uint32_t end = cursor[h], beg = h ? cursor[h - 1] : 0u;
       const uint32_t rem = M - p < kMaxLen ? M - p : kMaxLen;
+      spent += end - beg;
       for (uint32_t i = beg; i < end; i++) {
-        const uint32_t iq = items[i];
-        spent++;
-        if (iq >= ip || ip - iq > kWindow || px[iq] != x) continue;
-        const uint32_t d = ip - iq;
+        const uint32_t it = items[i];
+        const uint32_t d = ip - (it & (kSpSources - 1));
+        if ((it ^ tag) >= kSpSources || d - 1 >= kWindow) continue;  // another value, or not one of the 1024 before p
+        const uint32_t iq = ip - d;
         const uint32_t maxl = d < rem ? d : rem;  // no overlap with the source, at most 128, inside the image
+        // what this candidate must reach to replace the best so far: longer, or as long and farther (lz77.h:68)
+        const uint32_t need = (key >> 11) + (d > (key & 2047u) ? 0u : 1u);
+        if (maxl < need) continue;
+        if (need > 1 && px[iq + need - 1] != px[ip + need - 1]) continue;
         uint32_t l = 1;
         while (l < maxl && px[iq + l] == px[ip + l]) l++;
         spent += l;
-        const uint32_t kk = (l << 11) | d;  // longest, then farthest (lz77.h:68)
-        key = kk > key ? kk : key;
+        if (l < need) continue;
+        key = (l << 11) | d;
       }
       if (spent > kSpBudget) over = true;
       if (p == M - 1) key = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
@@ -413,7 +426,7 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
   __syncthreads();
   if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
 #pragma unroll
-  for (uint32_t k = 0; k < kLzTile / 256; k++) {
+  for (uint32_t k = 0; k < kSpTile / 256; k++) {
     const uint32_t p = a + k * 256 + tid;
     if (p < b) match[pos0 + p] = out[k];
   }
@@ -1084,7 +1097,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix);
   (void)hipEventRecord(e->ev[2], s);
   if (e->match_mode == 0)
-    hipLaunchKernelGGL(k_lz77_sparse, dim3(gsb * (kSuper / kLzTile)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, dense);
+    hipLaunchKernelGGL(k_lz77_sparse, dim3(gsb * (kSuper / kSpTile)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, dense);
   hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match,
                      e->match_mode == 0 ? dense : (const uint8_t *)nullptr);
   (void)hipEventRecord(e->ev[3], s);
