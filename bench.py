@@ -131,12 +131,17 @@ def main():
     if not args.no_verify:
         dec = webp_amd.Decoder(local_rank)
         d_dec = torch.empty((batch, npx), dtype=torch.int32, device=dev)
+        dargs = ([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], ws, hs,
+                 [d_dec[k].data_ptr() for k in range(batch)])
+        stt = dec.decode_device(*dargs)          # first call allocates the workspace
+        verify = bool((stt == 0).all() and torch.equal(d_dec, d_in))
+        d_dec.zero_()
+        torch.cuda.synchronize()
         td = time.perf_counter()
-        stt = dec.decode_device([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], ws, hs,
-                                [d_dec[k].data_ptr() for k in range(batch)])
+        stt = dec.decode_device(*dargs)
         torch.cuda.synchronize()
         td = time.perf_counter() - td
-        verify = bool((stt == 0).all() and torch.equal(d_dec, d_in))
+        verify = verify and bool((stt == 0).all() and torch.equal(d_dec, d_in))
         decode_mps = batch * npx / 1e6 / td
         del d_dec
 
@@ -165,7 +170,7 @@ def main():
             "device_ms_per_step": 1e3 * float(np.mean(dev_times)),
             "stage_ms_per_step": {k2: 1e3 * v / args.steps for k2, v in stage_acc.items()},
             "roundtrip_verified": verify,
-            "decode_megapixels_per_sec_untimed_check": decode_mps,
+            "decode_megapixels_per_sec": decode_mps,
             "roofline": {"kernel": "k_lz77", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": 1e3 * lz_avg, "algorithmic_bytes_per_launch": LZ77_BYTES_PER_PIXEL * batch * npx},

@@ -27,3 +27,11 @@ mp = batch * w * h / 1e6
 print("mode %d batch %d %dx%d: %.1f MP/s, bpp %.2f, dense tiles %s" % (mode, batch, w, h, mp / enc.last_device_seconds(), 8.0 * lens.sum() / (batch * w * h), enc.last_dense_tiles()))
 print("  " + "  ".join("%s %.2f" % (k, 1e3 * v) for k, v in ss.items()) + "  (ms)")
 print("  ns/px: " + "  ".join("%s %.3f" % (k, 1e9 * v / (mp * 1e6)) for k, v in ss.items()))
+
+dec = webp_amd.Decoder()
+d_dec = torch.empty((batch, w * h), dtype=torch.int32, device="cuda")
+args = ([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], [w] * batch, [h] * batch, [d_dec[k].data_ptr() for k in range(batch)])
+for it in range(2):
+    stt = dec.decode_device(*args)
+assert (stt == 0).all() and torch.equal(d_dec, d_in)
+print("  decode: %.1f MP/s (device time %.1f ms)" % (mp / dec.last_device_seconds(), 1e3 * dec.last_device_seconds()))

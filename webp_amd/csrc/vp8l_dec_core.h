@@ -60,11 +60,13 @@ struct BitSrc {
 // The reference walks a node tree one bit at a time (huffman_io.h:85-91); the symbol that walk
 // reaches is the canonical-code symbol, so a table gives the same result: codes of up to
 // kLutBits bits resolve in one lookup, longer ones by the per-length counts.
-constexpr int kLutBits = 8;
+constexpr int kLutBits = 10;
 constexpr uint16_t kLongCode = 0xffff;
 struct HuffTable {
   uint16_t lut[1 << kLutBits];  // (symbol << 4) | length; kLongCode = longer than kLutBits; a one-leaf code has length 0
   uint16_t count[kSaneCodeLen + 1];
+  uint16_t index[kSaneCodeLen + 1];  // symbols with shorter codes (position of the first code of this length in `sorted`)
+  uint32_t first[kSaneCodeLen + 1];  // first canonical code of each length
   uint16_t single;              // the symbol of a one-leaf code (it consumes no bits), else 0xffff
   uint16_t maxlen;
   uint32_t sorted_off;          // where this code's (length, symbol)-ordered symbols start in `sorted`
@@ -121,6 +123,8 @@ VP8L_HD int build_table(HuffTable &t, uint16_t *sorted, const uint8_t *lengths, 
     code = (code + (l > 1 ? t.count[l - 1] : 0)) << 1;
     s.next[l] = code;
     s.off[l + 1] = (uint16_t)(s.off[l] + t.count[l]);
+    t.first[l] = code;
+    t.index[l] = s.off[l];
   }
   for (int i = 0; i < (1 << kLutBits); i++) t.lut[i] = kLongCode;
   for (int i = 0; i < n; i++) {
@@ -149,6 +153,8 @@ VP8L_HD int build_simple(HuffTable &t, uint16_t *sorted, int nsym, uint32_t s0, 
   }
   t.maxlen = 1;
   t.count[1] = 2;
+  t.first[1] = 0;
+  t.index[1] = 0;
   sorted[0] = (uint16_t)s0;
   sorted[1] = (uint16_t)s1;
   for (int i = 0; i < (1 << kLutBits); i++) t.lut[i] = (uint16_t)((((i & 1) ? s1 : s0) << 4) | 1);
@@ -173,7 +179,7 @@ VP8L_HD uint32_t read_sym(BitSrc &br, const HuffTable &t, const uint16_t *sorted
 }
 
 // ---- state machine ---------------------------------------------------------------------------
-enum : uint32_t { kEvDone = 0, kEvCopy = 1, kEvRefill = 2 };
+enum : uint32_t { kEvDone = 0, kEvCopy = 1, kEvRefill = 2, kEvPixels = 3 };
 enum : uint32_t {
   kPhStart = 0, kPhXform, kPhImgBegin, kPhPixels, kPhAfterCopy, kPhPaletteFix, kPhMain, kPhMetaDone,
   kPhGroups, kPhDone
@@ -235,6 +241,10 @@ struct DecAccel {
   uint32_t *ring = nullptr;
   uint32_t ring_mask = 0;
   const GroupTables *g0 = nullptr;
+  // the driver decodes the pixels of one-group, cache-less coded images itself (kEvPixels): it must
+  // leave st.fill = st.total, the bit reader state and st.phase = st.after (or a failure) behind
+  bool driver_pixels = false;
+  bool on = false;  // win, ring and g0 are set (tested instead of the pointers)
 };
 constexpr uint32_t kInlineCopyMax = 16;   // longer copies go to the driver (kEvCopy)
 constexpr uint32_t kWinPixelSlack = 64;   // bytes one token can need at most, with room to spare
@@ -346,8 +356,8 @@ VP8L_HD uint32_t decode_pixels(DecState &st, BitSrc &br, const DecAccel &acc) {
   uint32_t *cache = st.cache;
   uint32_t *ring = acc.ring;
   const uint32_t rmask = acc.ring_mask;
-  const bool refillable = acc.win != nullptr && !st.win_final;
-  const GroupTables *g = acc.g0 ? acc.g0 : st.groups;
+  const bool refillable = acc.on && !st.win_final;
+  const GroupTables *g = acc.on ? acc.g0 : st.groups;
   const GroupTables *groups = st.groups;
   const uint32_t *meta = st.meta;
   const uint32_t meta_bits = st.meta_bits, meta_xsize = st.meta_xsize;
@@ -372,7 +382,7 @@ VP8L_HD uint32_t decode_pixels(DecState &st, BitSrc &br, const DecAccel &acc) {
       // The reference copies without checking (vp8l.h:298-300); a reference before the start
       // or past the end of the image is reported instead of reading/writing out of bounds.
       if (dist > fill || fill + length > total) { st.status = kErrInvalidVp8l; rc = kPxFail; break; }
-      if (ring && length <= kInlineCopyMax && dist <= rmask + 1) {
+      if (acc.on && length <= kInlineCopyMax && dist <= rmask + 1) {
         for (uint32_t i = 0; i < length; i++) {  // in order: an overlapping reference repeats its own output
           const uint32_t v = ring[(uint32_t)(fill - dist) & rmask];
           ring[(uint32_t)fill & rmask] = v;
@@ -389,7 +399,7 @@ VP8L_HD uint32_t decode_pixels(DecState &st, BitSrc &br, const DecAccel &acc) {
     } else {
       px = cache[S - 280];
     }
-    if (ring) ring[(uint32_t)fill & rmask] = px;
+    if (acc.on) ring[(uint32_t)fill & rmask] = px;
     dst[fill++] = px;
     // The reference inserts lazily (vp8l.h:286-288,308-310,315-324) but always in pixel order and
     // always before the next lookup, which is what inserting every pixel at once gives.
@@ -405,11 +415,11 @@ VP8L_HD uint32_t decode_pixels(DecState &st, BitSrc &br, const DecAccel &acc) {
 VP8L_HD uint32_t dec_step(DecState &st, const DecAccel &acc = DecAccel()) {
   BitSrc br;
   br.data = st.data; br.len = st.len; br.bytepos = st.bytepos; br.buf = st.buf; br.cnt = st.cnt;
-  br.win = acc.win; br.win_lo = st.win_lo; br.win_hi = acc.win ? st.win_hi : 0;
+  br.win = acc.win; br.win_lo = st.win_lo; br.win_hi = acc.on ? st.win_hi : 0;
 #define VP8L_SAVE_BR() do { st.bytepos = br.bytepos; st.buf = br.buf; st.cnt = br.cnt; } while (0)
 #define VP8L_FAIL(code) do { st.status = (code); st.phase = kPhDone; VP8L_SAVE_BR(); return kEvDone; } while (0)
   for (;;) {
-    if (acc.win && !st.win_final && st.phase != kPhDone && br.bytepos + kWinPhaseSlack > br.win_hi) { VP8L_SAVE_BR(); return kEvRefill; }
+    if (acc.on && !st.win_final && st.phase != kPhDone && br.bytepos + kWinPhaseSlack > br.win_hi) { VP8L_SAVE_BR(); return kEvRefill; }
     switch (st.phase) {
       case kPhStart: {  // ReadInfo vp8l.h:83-94
         (void)br.get(32);
@@ -465,6 +475,10 @@ VP8L_HD uint32_t dec_step(DecState &st, const DecAccel &acc = DecAccel()) {
         break;
       }
       case kPhPixels: {
+        if (acc.driver_pixels && st.ngroups == 1 && st.cache_bits == 0 && st.fill == 0 && st.total < 0x7fffffffu) {
+          VP8L_SAVE_BR();
+          return kEvPixels;
+        }
         const uint32_t rc = st.ngroups == 1 ? decode_pixels<true>(st, br, acc) : decode_pixels<false>(st, br, acc);
         if (rc == kPxFail) { st.phase = kPhDone; VP8L_SAVE_BR(); return kEvDone; }
         if (rc == kPxCopy) { st.phase = kPhAfterCopy; VP8L_SAVE_BR(); return kEvCopy; }

@@ -41,8 +41,235 @@ struct DecResult {  // device-written
   XformRec xf[4];
 };
 
-constexpr uint32_t kRingPixels = 2048;   // recent output kept in LDS for short back references
+constexpr uint32_t kRingPixels = 2048;   // recent output kept in LDS for back references
+constexpr uint32_t kRingNear = 1920;     // references up to this distance read the ring, farther ones HBM
 constexpr uint32_t kStreamWindow = 2048;  // bytes of the stream kept in LDS
+
+// ---------------------------------------------------------------------------------------------
+// Pixels of a coded image with one Huffman group and no colour cache, decoded by the whole wave.
+// A single reader is bound by the chain symbol -> code length -> position of the next symbol: about
+// a thousand cycles per literal pixel for one wave.  Here lane o decodes the literal that WOULD start
+// at bit o of a 128-bit buffer (four chained table lookups, all 64 lanes at once); the true starts
+// are then found by hopping from literal to literal with lane reads of the lengths, and every lane
+// that holds a true start stores its pixel.  One round resolves every literal inside 64 bits.
+// Anything else (a back reference, a code longer than the lookup table) is decoded uniformly by
+// the wave.  Everything that steers the loop is wave-uniform (scalar).
+// Output goes to an LDS ring and from there to HBM in aligned blocks of 64 pixels; back references
+// are copied by the wave, from the ring when they are near.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+struct WaveBits {  // all members wave-uniform
+  uint64_t lo, hi;  // the next `cnt` bits of the stream, bit 0 of lo first; zero above cnt
+  uint32_t cnt;
+  uint32_t widx;    // next word of the window
+  uint64_t win_lo;  // stream offset of the window
+};
+
+template <class WinPtr>
+__device__ __forceinline__ void window_load(WinPtr win, const DecImage &im, uint64_t lo, uint32_t lane) {
+  // the stream is 4-byte aligned (checked by the host); bytes past its end read as zero
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(im.data);
+  for (uint32_t i = lane; i < kStreamWindow / 4; i += 64) {
+    const uint64_t pos = lo + 4ull * i;
+    uint32_t v = 0;
+    if (pos + 4 <= im.len) v = src[pos >> 2];
+    else for (uint32_t k = 0; k < 4; k++) if (pos + k < im.len) v |= (uint32_t)im.data[pos + k] << (8 * k);
+    win[i] = v;
+  }
+}
+
+template <class WinPtr>
+__device__ __forceinline__ void wb_refill(WaveBits &b, WinPtr win, const DecImage &im, uint32_t lane) {  // more than 96 bits
+  while (b.cnt <= 96) {
+    if (b.widx == kStreamWindow / 4) {
+      b.win_lo += kStreamWindow;
+      __syncthreads();
+      window_load(win, im, b.win_lo, lane);
+      __syncthreads();
+      b.widx = 0;
+    }
+    const uint64_t w = uni(win[b.widx]);
+    if (b.cnt < 64) {
+      b.lo |= w << b.cnt;
+      if (b.cnt > 32) b.hi |= w >> (64 - b.cnt);
+    } else {
+      b.hi |= w << (b.cnt - 64);
+    }
+    b.cnt += 32;
+    b.widx++;
+  }
+}
+__device__ __forceinline__ void wb_skip(WaveBits &b, uint32_t n) {  // n <= cnt
+  if (n >= 64) { b.lo = b.hi >> (n - 64); b.hi = 0; }
+  else if (n) { b.lo = (b.lo >> n) | (b.hi << (64 - n)); b.hi >>= n; }
+  b.cnt -= n;
+}
+__device__ __forceinline__ uint32_t wb_get(WaveBits &b, uint32_t n) {  // n <= 32 and available
+  const uint32_t v = (uint32_t)(b.lo & ((1ull << n) - 1ull));
+  wb_skip(b, n);
+  return v;
+}
+
+// One symbol, uniformly (codes are at most 32 bits long; at least that many are buffered).  A code
+// longer than the lookup table is found by all lengths at once: lane l tests whether the first l
+// bits are a canonical code of length l; the shortest hit is the code (prefix-free).
+template <class Table, class Sorted>
+__device__ __forceinline__ uint32_t wb_sym(WaveBits &b, const Table &t, Sorted sorted, uint32_t lane) {
+  const uint32_t bits = (uint32_t)b.lo;
+  const uint32_t e = uni(t.lut[bits & ((1u << kLutBits) - 1u)]);
+  if (e != kLongCode) { wb_skip(b, e & 15u); return e >> 4; }
+  const uint32_t maxlen = uni(t.maxlen);
+  uint32_t d = 0;
+  bool hit = false;
+  if (lane >= 1 && lane <= maxlen) {
+    d = (__brev(bits) >> (32 - lane)) - t.first[lane];
+    hit = d < t.count[lane];
+  }
+  const uint64_t hits = __ballot(hit);
+  if (hits == 0) { wb_skip(b, maxlen); return 0; }  // unreachable for a complete code
+  const uint32_t len = (uint32_t)__builtin_ctzll(hits);
+  uint32_t sym = 0;
+  if (hit) sym = sorted[t.sorted_off + t.index[lane] + d];
+  wb_skip(b, len);
+  return lane_read(sym, len);
+}
+
+// A function of its own: inlined into the kernel's state-machine loop it is compiled far worse.
+// Its arguments point into LDS and are typed so (ds_read / ds_write instead of flat accesses).
+#define VP8L_LDS __attribute__((address_space(3)))
+__device__ __noinline__ void wave_decode_pixels(VP8L_LDS DecState *st_, const VP8L_LDS GroupTables *g_, VP8L_LDS uint32_t *ring,
+                                                VP8L_LDS uint32_t *win, const DecImage &im, uint32_t lane) {
+  VP8L_LDS DecState &st = *st_;
+  const VP8L_LDS GroupTables &g = *g_;
+  WaveBits b;
+  b.lo = uni64(st.buf);
+  b.hi = 0;
+  b.cnt = uni(st.cnt);
+  {
+    const uint64_t bytepos = uni64(st.bytepos), wlo = uni64(st.win_lo), whi = uni64(st.win_hi);
+    if (bytepos >= wlo && bytepos + 4 <= whi && whi == wlo + kStreamWindow) {
+      b.win_lo = wlo;
+      b.widx = (uint32_t)(bytepos - wlo) >> 2;
+    } else {
+      b.win_lo = bytepos;
+      b.widx = 0;
+      __syncthreads();
+      window_load(win, im, bytepos, lane);
+      __syncthreads();
+    }
+  }
+  const uint32_t total = uni((uint32_t)st.total), xsize = uni(st.xsize);
+  uint32_t *dst = st.dst;
+  const VP8L_LDS uint16_t *lutG = g.t[kGreen].lut, *lutR = g.t[kRed].lut, *lutB = g.t[kBlue].lut, *lutA = g.t[kAlpha].lut;
+  uint32_t fill = 0, flushed = 0;  // flushed: multiple of 64, everything before it is in HBM
+  int32_t status = kOk;
+  while (fill < total) {
+    wb_refill(b, win, im, lane);
+    // ---- every lane: the literal that would start at bit `lane`
+    uint64_t w = b.lo >> lane;
+    if (lane) w |= b.hi << (64 - lane);
+    const uint32_t eG = lutG[(uint32_t)w & ((1u << kLutBits) - 1u)];
+    uint32_t n = eG & 15u;
+    const uint32_t eR = lutR[(uint32_t)(w >> n) & ((1u << kLutBits) - 1u)];
+    n += eR & 15u;
+    const uint32_t eB = lutB[(uint32_t)(w >> n) & ((1u << kLutBits) - 1u)];
+    n += eB & 15u;
+    const uint32_t eA = lutA[(uint32_t)(w >> n) & ((1u << kLutBits) - 1u)];
+    n += eA & 15u;
+    const bool lit = eG < (256u << 4) && eR != kLongCode && eB != kLongCode && eA != kLongCode && n != 0;
+    const uint32_t hop = lit ? n : 0u;  // 0: not a literal this path handles
+    const uint32_t px = ((eA >> 4) << 24) | ((eR >> 4) << 16) | ((eG >> 4) << 8) | (eB >> 4);
+    // ---- the true starts: hop from literal to literal
+    uint64_t starts = 0;
+    uint32_t o = 0, found = 0;
+    const uint32_t room = total - fill;
+    while (o < 64 && found < room) {
+      const uint32_t h = lane_read(hop, o);
+      if (h == 0 || o + h > b.cnt) break;  // not a plain literal, or one that runs past the buffered bits
+      starts |= 1ull << o;
+      o += h;
+      found++;
+    }
+    if (found) {
+      const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u));
+      if ((starts >> lane) & 1ull) ring[(fill + below) & (kRingPixels - 1)] = px;
+      wb_skip(b, o);
+      fill += found;
+      while (fill - flushed >= 64) {
+        dst[flushed + lane] = ring[(flushed + lane) & (kRingPixels - 1)];
+        flushed += 64;
+      }
+      continue;
+    }
+    // ---- the token at bit 0 is something else: decode it uniformly
+    const uint32_t S = wb_sym(b, g.t[kGreen], g.sorted, lane);
+    if (S < 256) {
+      const uint32_t r2 = wb_sym(b, g.t[kRed], g.sorted, lane);
+      wb_refill(b, win, im, lane);
+      const uint32_t b2 = wb_sym(b, g.t[kBlue], g.sorted, lane);
+      const uint32_t a2 = wb_sym(b, g.t[kAlpha], g.sorted, lane);
+      if (lane == 0) ring[fill & (kRingPixels - 1)] = (a2 << 24) | (r2 << 16) | (S << 8) | b2;
+      fill++;
+    } else if (S < 280) {
+      uint32_t base, nb;
+      prefix_decode_base(S - 256, base, nb);
+      const uint32_t length = base + wb_get(b, nb);
+      prefix_decode_base(wb_sym(b, g.t[kDist], g.sorted, lane), base, nb);  // 32 + 10 + 32 bits at most so far
+      wb_refill(b, win, im, lane);
+      const uint32_t dcode = base + wb_get(b, nb);
+      const uint32_t dist = code_to_dist(xsize, dcode);
+      // The reference copies without checking (vp8l.h:298-300); a reference before the start
+      // or past the end of the image is reported instead of reading/writing out of bounds.
+      if (dist > fill || length > total - fill) { status = kErrInvalidVp8l; break; }
+      const bool near = dist <= kRingNear;
+      if (!near) __threadfence_block();
+      for (uint32_t c = 0; c < length; c += 64) {
+        const uint32_t e = c + lane;
+        if (e < length) {
+          // element e of the copy equals element (e mod dist) of the source: right for overlapping references too
+          const uint32_t s = fill - dist + (dist >= length ? e : e % dist);
+          const uint32_t v = near ? ring[s & (kRingPixels - 1)] : dst[s];
+          ring[(fill + e) & (kRingPixels - 1)] = v;
+        }
+        // completed blocks of 64 go out before the ring can wrap onto them
+        const uint32_t upto = fill + (c + 64 < length ? c + 64 : length);
+        while (upto - flushed >= 64) {
+          dst[flushed + lane] = ring[(flushed + lane) & (kRingPixels - 1)];
+          flushed += 64;
+        }
+      }
+      fill += length;
+      continue;
+    } else {
+      status = kErrInvalidVp8l;  // no colour cache: no such symbol in a 280-symbol alphabet
+      break;
+    }
+    if (fill - flushed >= 64) {
+      dst[flushed + lane] = ring[(flushed + lane) & (kRingPixels - 1)];
+      flushed += 64;
+    }
+  }
+  if (status == kOk && flushed + lane < fill) dst[flushed + lane] = ring[(flushed + lane) & (kRingPixels - 1)];
+  __threadfence_block();
+  // hand the reader back as the machine keeps it: at most 64 buffered bits, whole words un-read
+  uint32_t unread = 0;
+  while (b.cnt > 64) { b.cnt -= 32; unread++; }
+  const bool in_window = b.widx >= unread;
+  if (lane == 0) {
+    st.fill = fill;
+    st.buf = b.cnt == 64 ? b.lo : b.lo & ((1ull << b.cnt) - 1ull);
+    st.cnt = b.cnt;
+    st.bytepos = b.win_lo + 4ull * b.widx - 4ull * unread;
+    st.win_lo = in_window ? b.win_lo : 0;
+    st.win_hi = in_window ? b.win_lo + kStreamWindow : 0;
+    st.win_final = in_window && b.win_lo + kStreamWindow >= im.len;
+    if (status == kOk) st.phase = st.after;
+    else { st.status = status; st.phase = kPhDone; }
+  }
+}
 
 __global__ __launch_bounds__(64) void k_decode_entropy(const DecImage *__restrict__ imgs, DecResult *__restrict__ res) {
   __shared__ DecState st;
@@ -57,6 +284,8 @@ __global__ __launch_bounds__(64) void k_decode_entropy(const DecImage *__restric
   acc.ring = ring;
   acc.ring_mask = kRingPixels - 1;
   acc.g0 = &g0;
+  acc.driver_pixels = true;
+  acc.on = true;
   if (lane == 0) {
     dec_init(st, im.data, im.len, im.out, im.aux, im.aux_cap, &g0, im.groups, im.group_cap, im.cache);
     st.w = im.w;
@@ -69,17 +298,12 @@ __global__ __launch_bounds__(64) void k_decode_entropy(const DecImage *__restric
     ev = (uint32_t)__shfl((int)ev, 0, 64);
     if (ev == kEvDone) break;
     __syncthreads();  // lane 0's request (LDS) and pixel stores (HBM) before the wave acts on them
-    if (ev == kEvRefill) {
-      // the stream is 4-byte aligned (checked by the host); bytes past its end read as zero
+    if (ev == kEvPixels) {
+      wave_decode_pixels((VP8L_LDS DecState *)&st, (const VP8L_LDS GroupTables *)&g0, (VP8L_LDS uint32_t *)ring,
+                         (VP8L_LDS uint32_t *)win, im, lane);
+    } else if (ev == kEvRefill) {
       const uint64_t lo = st.bytepos;
-      const uint32_t *src = reinterpret_cast<const uint32_t *>(im.data);
-      for (uint32_t i = lane; i < kStreamWindow / 4; i += 64) {
-        const uint64_t pos = lo + 4ull * i;
-        uint32_t v = 0;
-        if (pos + 4 <= im.len) v = src[pos >> 2];
-        else for (uint32_t k = 0; k < 4; k++) if (pos + k < im.len) v |= (uint32_t)im.data[pos + k] << (8 * k);
-        win[i] = v;
-      }
+      window_load(win, im, lo, lane);
       if (lane == 0) { st.win_lo = lo; st.win_hi = lo + kStreamWindow; st.win_final = lo + kStreamWindow >= im.len; }
     } else {
       __threadfence_block();
