@@ -563,34 +563,59 @@ __device__ __forceinline__ uint32_t flag_at(const uint32_t *__restrict__ flags, 
 // =============================================================================================
 // Histograms (vp8l.h:516-535): LDS-private per block, merged into the image's 5x280 counters.
 // =============================================================================================
+// One count per active lane.  Lanes that all hold the same symbol (an opaque alpha channel, a flat
+// colour plane) would serialise on one LDS address: then one lane adds the number of lanes.
+__device__ __forceinline__ void histo_add(uint32_t *h, uint32_t sym) {
+  const uint64_t active = __ballot(1);
+  const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym);
+  if (__ballot(sym == first) == active) {
+    if ((uint32_t)__builtin_ctzll(active) == (threadIdx.x & 63u)) atomicAdd(&h[first], (uint32_t)__popcll(active));
+  } else {
+    atomicAdd(&h[sym], 1u);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_histogram(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                    const uint32_t *__restrict__ sb_first, uint32_t n,
                                                    const uint32_t *__restrict__ pix, const uint32_t *__restrict__ match,
                                                    const uint32_t *__restrict__ flags, uint32_t *__restrict__ histo) {
   __shared__ uint32_t h[kNumCodes * kCodeStride];
-  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  // one superblock per workgroup: the merge into the image's counters (up to 1400 global atomics) is paid once per 16384 positions
+  const uint32_t sb = blockIdx.x, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   const uint32_t M = st[img].M;
-  const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
+  const uint32_t p0 = (sb - sb_first[img]) * kSuper;
   if (p0 >= M) return;
   for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) h[i] = 0;
   __syncthreads();
   const uint64_t pos0 = imgs[img].pos0;
-  for (uint32_t k = 0; k < kUnit / 256; k++) {
-    const uint32_t p = p0 + k * 256 + tid;
-    if (p >= M || !flag_at(flags, pos0 + p)) continue;
-    const uint32_t m = match[pos0 + p], len = m & 0xff;
-    if (len == 0) {
-      const uint32_t px = pix[pos0 + p];
-      atomicAdd(&h[kGreen * kCodeStride + ((px >> 8) & 0xff)], 1u);
-      atomicAdd(&h[kRed * kCodeStride + ((px >> 16) & 0xff)], 1u);
-      atomicAdd(&h[kBlue * kCodeStride + (px & 0xff)], 1u);
-      atomicAdd(&h[kAlpha * kCodeStride + (px >> 24)], 1u);
-    } else {
-      uint32_t sym, nb, eb;
-      prefix_encode(len, sym, nb, eb);
-      atomicAdd(&h[kGreen * kCodeStride + 256 + sym], 1u);
-      prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);  // distance code, computed with the match
-      atomicAdd(&h[kDist * kCodeStride + sym], 1u);
+  // four consecutive positions per thread, everything loaded before anything is used (the arrays have
+  // readable slack past M): dependent flag -> match -> pixel loads would leave the kernel latency-bound
+#pragma unroll 2
+  for (uint32_t k = 0; k < kSuper / 1024; k++) {
+    const uint32_t p = p0 + (k * 256 + tid) * 4;
+    if (p >= M) break;
+    const uint4 m4 = *reinterpret_cast<const uint4 *>(match + pos0 + p);
+    const uint4 x4 = *reinterpret_cast<const uint4 *>(pix + pos0 + p);
+    uint32_t fl = (flags[(pos0 + p) >> 5] >> ((pos0 + p) & 31)) & 15u;
+    if (p + 4 > M) fl &= (1u << (M - p)) - 1u;
+    const uint32_t mm[4] = {m4.x, m4.y, m4.z, m4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (!((fl >> j) & 1u)) continue;
+      const uint32_t m = mm[j], len = m & 0xff;
+      if (len == 0) {
+        const uint32_t px = xx[j];
+        histo_add(&h[kGreen * kCodeStride], (px >> 8) & 0xff);
+        histo_add(&h[kRed * kCodeStride], (px >> 16) & 0xff);
+        histo_add(&h[kBlue * kCodeStride], px & 0xff);
+        histo_add(&h[kAlpha * kCodeStride], px >> 24);
+      } else {
+        uint32_t sym, nb, eb;
+        prefix_encode(len, sym, nb, eb);
+        atomicAdd(&h[kGreen * kCodeStride + 256 + sym], 1u);
+        prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);  // distance code, computed with the match
+        atomicAdd(&h[kDist * kCodeStride + sym], 1u);
+      }
     }
   }
   __syncthreads();
@@ -660,12 +685,10 @@ __device__ __forceinline__ uint32_t token_bit_count(const uint8_t *lens, const b
   return bits;
 }
 
-// sum over the 16 lanes of a row, valid in the row's last lane
-__device__ __forceinline__ uint32_t row16_sum_u32(uint32_t v) {
+// sum over 4 adjacent lanes, valid in the last of them
+__device__ __forceinline__ uint32_t quad_sum_u32(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
   return v;
 }
 
@@ -690,16 +713,24 @@ __global__ __launch_bounds__(256) void k_bitcount(const EncImage *__restrict__ i
   __syncthreads();
   const uint64_t pos0 = imgs[img].pos0;
   uint32_t total = 0;
-  for (uint32_t k = 0; k < kUnit / 256; k++) {
-    const uint32_t p = p0 + k * 256 + tid;
+  // four consecutive positions per thread, all loads of an iteration issued together
+#pragma unroll 2
+  for (uint32_t k = 0; k < kUnit / 1024; k++) {
+    const uint32_t p = p0 + (k * 256 + tid) * 4;
     uint32_t bits = 0;
-    if (p < M && flag_at(flags, pos0 + p)) {
-      const uint32_t m = match[pos0 + p];
-      bits = token_bit_count(lens, wr, (m & 0xff) ? 0u : pix[pos0 + p], m);
+    if (p < M) {
+      const uint4 m4 = *reinterpret_cast<const uint4 *>(match + pos0 + p);
+      const uint4 x4 = *reinterpret_cast<const uint4 *>(pix + pos0 + p);
+      uint32_t fl = (flags[(pos0 + p) >> 5] >> ((pos0 + p) & 31)) & 15u;
+      if (p + 4 > M) fl &= (1u << (M - p)) - 1u;
+      if (fl & 1u) bits += token_bit_count(lens, wr, x4.x, m4.x);
+      if (fl & 2u) bits += token_bit_count(lens, wr, x4.y, m4.y);
+      if (fl & 4u) bits += token_bit_count(lens, wr, x4.z, m4.z);
+      if (fl & 8u) bits += token_bit_count(lens, wr, x4.w, m4.w);
     }
     total += bits;
-    const uint32_t g = row16_sum_u32(bits);
-    if ((tid & 15) == 15 && (p - 15) < M) group_bits[(pos0 + p) >> 4] = (uint16_t)g;
+    const uint32_t g = quad_sum_u32(bits);  // positions p-12 .. p+3: one group
+    if ((tid & 3) == 3 && (p - 12) < M) group_bits[(pos0 + p) >> 4] = (uint16_t)g;
   }
   const uint32_t s = wave_sum_u32(total);
   if ((tid & 63) == 0) wsum[tid >> 6] = s;
@@ -815,15 +846,18 @@ __device__ __forceinline__ void emit_token_packed(Put &put, const uint2 *tab, co
 template <class Put>
 __device__ __forceinline__ void emit_group(Put &put, const uint2 *tab, const bool *wr, const uint32_t *__restrict__ px,
                                            const uint32_t *__restrict__ mt, uint32_t fl) {
+  uint4 m4 = *reinterpret_cast<const uint4 *>(mt), p4 = *reinterpret_cast<const uint4 *>(px);
 #pragma unroll 1
   for (int g = 0; g < 4; g++, fl >>= 4) {
-    if ((fl & 15u) == 0) continue;
-    const uint4 m4 = *reinterpret_cast<const uint4 *>(mt + 4 * g);
-    const uint4 p4 = *reinterpret_cast<const uint4 *>(px + 4 * g);
-    if (fl & 1u) emit_token_packed(put, tab, wr, p4.x, m4.x);
-    if (fl & 2u) emit_token_packed(put, tab, wr, p4.y, m4.y);
-    if (fl & 4u) emit_token_packed(put, tab, wr, p4.z, m4.z);
-    if (fl & 8u) emit_token_packed(put, tab, wr, p4.w, m4.w);
+    const uint4 mc = m4, pc = p4;
+    if (g < 3) {  // the next four while these are written
+      m4 = *reinterpret_cast<const uint4 *>(mt + 4 * g + 4);
+      p4 = *reinterpret_cast<const uint4 *>(px + 4 * g + 4);
+    }
+    if (fl & 1u) emit_token_packed(put, tab, wr, pc.x, mc.x);
+    if (fl & 2u) emit_token_packed(put, tab, wr, pc.y, mc.y);
+    if (fl & 4u) emit_token_packed(put, tab, wr, pc.z, mc.z);
+    if (fl & 8u) emit_token_packed(put, tab, wr, pc.w, mc.w);
   }
   put.finish();
 }
@@ -1105,7 +1139,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   hipLaunchKernelGGL(k_parse_chain, dim3(nl), dim3(256), 0, s, st, sbf, sx, entry);
   hipLaunchKernelGGL(k_parse_mark, dim3(gsb), dim3(128), 0, s, imgs, st, sbf, nl, match, entry, flags);
   (void)hipEventRecord(e->ev[4], s);
-  hipLaunchKernelGGL(k_histogram, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, histo);
+  hipLaunchKernelGGL(k_histogram, dim3(gsb), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, histo);
   (void)hipEventRecord(e->ev[5], s);
   hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(64), 0, s, imgs, st, histo, tables, d_out);
   (void)hipEventRecord(e->ev[6], s);
