@@ -39,6 +39,8 @@ struct HuffScratch {
   uint32_t wt[2 * kCodeStride];
   uint16_t parent[2 * kCodeStride];
   uint16_t ord[kCodeStride];
+  uint16_t stack[kCodeStride];
+  uint16_t depth[2 * kCodeStride];
 };
 
 VP8L_HD uint32_t bit_reverse(uint32_t v, int len) {
@@ -54,47 +56,61 @@ VP8L_HD uint32_t bit_reverse(uint32_t v, int len) {
 // The reference keeps an array of roots sorted ascending by weight and, after joining the two
 // lightest, re-sorts with a stable sort with the new root in slot 0: the new root therefore
 // lands in front of every root of equal weight, and leaves of equal weight stay in symbol order.
-// That tie rule decides the lengths, so it is reproduced exactly: `ord` is that sorted array.
+// That tie rule decides the lengths, so it is reproduced exactly, in linear time after the sort:
+// joined weights never decrease, so the internal nodes are created in ascending weight order and
+// the array order among roots of one weight is: internal nodes newest first, then the leaves in
+// symbol order.  Leaves are taken from their sorted list, internal nodes from a stack that holds
+// the lightest run of equal-weight internal nodes (newest on top); later, heavier ones wait in
+// creation order (`pend`) and are moved to the stack run by run.
 // Returns the number of used symbols, or -3 (TooBigCodeLength, huffman_coding.h:410-413).
-// n <= kCodeStride.
-VP8L_HD int huffman_lengths(const uint32_t *histo, int n, int max_len, uint8_t *lengths, HuffScratch &s) {
+// n <= kCodeStride.  presorted_used >= 0: the caller has already filled s.wt[0..used) with the used
+// symbols' weights in symbol order and s.ord with the leaf ids sorted by (weight, id).
+VP8L_HD int huffman_lengths(const uint32_t *histo, int n, int max_len, uint8_t *lengths, HuffScratch &s, int presorted_used = -1) {
   int nn = 0;
-  for (int i = 0; i < n; i++) {
-    lengths[i] = 0;
-    if (histo[i]) { s.wt[nn] = histo[i]; s.parent[nn] = 0xffff; nn++; }
+  if (presorted_used < 0) {
+    for (int i = 0; i < n; i++)
+      if (histo[i]) s.wt[nn++] = histo[i];
+    // leaf k is the k-th used symbol; stable insertion sort of leaf ids by weight
+    for (int i = 0; i < nn; i++) {
+      int j = i;
+      const uint32_t w = s.wt[i];
+      while (j > 0 && s.wt[s.ord[j - 1]] > w) { s.ord[j] = s.ord[j - 1]; j--; }
+      s.ord[j] = (uint16_t)i;
+    }
+  } else {
+    nn = presorted_used;
   }
   const int used = nn;
+  for (int i = 0; i < n; i++) lengths[i] = 0;
   if (used == 0) return 0;
-  // leaf k is the k-th used symbol; stable insertion sort of leaf ids by weight
-  for (int i = 0; i < used; i++) {
-    int j = i;
-    const uint32_t w = s.wt[i];
-    while (j > 0 && s.wt[s.ord[j - 1]] > w) { s.ord[j] = s.ord[j - 1]; j--; }
-    s.ord[j] = (uint16_t)i;
-  }
-  int head = 0;  // ord[head..used) are the live roots
-  while (used - head > 1) {
-    const int a = s.ord[head], b = s.ord[head + 1];
-    const uint32_t w = s.wt[a] + s.wt[b];
-    s.wt[nn] = w;
-    s.parent[nn] = 0xffff;
-    s.parent[a] = s.parent[b] = (uint16_t)nn;
-    // first live root (past the two removed) that is not lighter than the new one
-    int lo = head + 2, hi = used;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (s.wt[s.ord[mid]] < w) lo = mid + 1; else hi = mid;
+  int lp = 0;          // next leaf in ord
+  int top = 0;         // stack height (s.stack)
+  int pend = used;     // internal nodes pend..nn-1 are not on the stack yet
+  uint32_t run_w = 0;  // weight of the run on the stack
+  for (int joins = used - 1; joins > 0; joins--) {
+    int pick[2];
+    for (int k = 0; k < 2; k++) {
+      if (top == 0 && pend < nn) {  // next run of equal-weight internal nodes, oldest first (newest ends on top)
+        run_w = s.wt[pend];
+        while (pend < nn && s.wt[pend] == run_w) s.stack[top++] = (uint16_t)pend++;
+      }
+      const bool have_leaf = lp < used;
+      if (top > 0 && (!have_leaf || run_w <= s.wt[s.ord[lp]])) pick[k] = s.stack[--top];
+      else pick[k] = s.ord[lp++];
     }
-    for (int i = head + 2; i < lo; i++) s.ord[i - 1] = s.ord[i];
-    s.ord[lo - 1] = (uint16_t)nn;
-    head++;
+    const uint32_t w = s.wt[pick[0]] + s.wt[pick[1]];
+    s.wt[nn] = w;
+    s.parent[pick[0]] = s.parent[pick[1]] = (uint16_t)nn;
+    if (top > 0 && pend == nn && w == run_w) { s.stack[top++] = (uint16_t)nn; pend = nn + 1; }  // joins the run on the stack, newest
     nn++;
   }
+  // depths from the root down (a parent is always created after its children)
+  s.depth[nn - 1] = 0;
+  for (int v = nn - 2; v >= 0; v--) s.depth[v] = (uint16_t)(s.depth[s.parent[v]] + 1);
   int maxl = 0, leaf = 0;
   for (int i = 0; i < n; i++) {
     if (!histo[i]) continue;
-    int d = 0;
-    for (int v = leaf; s.parent[v] != 0xffff; v = s.parent[v]) d++;
+    int d = s.depth[leaf];
     if (used == 1) d = 1;  // a lone symbol gets length 1 (huffman_coding.h:398-402)
     lengths[i] = (uint8_t)(d > 255 ? 255 : d);
     if (d > maxl) maxl = d;

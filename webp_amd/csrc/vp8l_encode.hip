@@ -256,9 +256,9 @@ __device__ __forceinline__ uint32_t lz77_chunk(uint32_t (&mis)[16], const uint32
 
 // a, b, M are wave-uniform (scalar registers).
 template <bool HEAD>
-__device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uint32_t *__restrict__ match, const uint32_t M,
-                                          const uint32_t a, const uint32_t b, const int lane, const uint32_t xsize,
-                                          const uint32_t xinv) {
+__device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uint32_t *__restrict__ match,
+                                          uint8_t *__restrict__ adv, const uint32_t M, const uint32_t a, const uint32_t b,
+                                          const int lane, const uint32_t xsize, const uint32_t xinv) {
   const uint32_t qs = (b + 127 < M - 1) ? b + 127 : M - 1;
   const int ctop = (int)(qs >> 4);
   const int cbot = (int)(a >> 4);
@@ -307,6 +307,7 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
           const uint32_t dist = (res & 1023u) + 1u;
           if (p == M - 1) len = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
           match[p] = len ? (len | (dist << 8) | (dist_to_code_inv(xsize, xinv, dist) << 19)) : 0u;
+          adv[p] = (uint8_t)(len ? len : 1u);
         }
       }
     } else {
@@ -344,7 +345,7 @@ static_assert(kSpSources == kWindow + kSpTile, "entry layout");
 __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                      const uint32_t *__restrict__ sb_first, uint32_t n,
                                                      const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
-                                                     uint8_t *__restrict__ dense_tile) {
+                                                     uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
   __shared__ uint32_t px[kSpSources + kMaxLen];
   __shared__ uint32_t cursor[kSpBuckets];  // counts, then insert positions; after the scatter cursor[h] = end of bucket h
   __shared__ uint32_t items[kSpSources];   // (low bits of the mixed pixel) << 11 | index in px
@@ -428,14 +429,17 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
 #pragma unroll
   for (uint32_t k = 0; k < kSpTile / 256; k++) {
     const uint32_t p = a + k * 256 + tid;
-    if (p < b) match[pos0 + p] = out[k];
+    if (p < b) {
+      match[pos0 + p] = out[k];
+      adv[pos0 + p] = (uint8_t)((out[k] & 0xff) ? (out[k] & 0xff) : 1u);
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                               const uint32_t *__restrict__ sb_first, uint32_t n,
                                               const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
-                                              const uint8_t *__restrict__ dense_tile) {
+                                              uint8_t *__restrict__ adv, const uint8_t *__restrict__ dense_tile) {
   constexpr uint32_t kPerSuper = kSuper / kLzBlock;
   const uint32_t blk = blockIdx.x, sb = blk / kPerSuper, img = find_image(sb_first, n, sb);
   const uint32_t M = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[img].M);
@@ -448,8 +452,8 @@ __global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs,
   // tiles the candidate-list kernel completed are done; it flags the ones it gave up on
   if (dense_tile && __builtin_amdgcn_readfirstlane((int)dense_tile[(pos0 + a) / kLzTile]) == 0) return;
   const uint32_t xsize = st[img].xsize, xinv = st[img].xinv;
-  if (a == 0) lz77_tile<true>(pix + pos0, match + pos0, M, a, b, lane, xsize, xinv);
-  else lz77_tile<false>(pix + pos0, match + pos0, M, a, b, lane, xsize, xinv);
+  if (a == 0) lz77_tile<true>(pix + pos0, match + pos0, adv + pos0, M, a, b, lane, xsize, xinv);
+  else lz77_tile<false>(pix + pos0, match + pos0, adv + pos0, M, a, b, lane, xsize, xinv);
 }
 
 // =============================================================================================
@@ -462,47 +466,44 @@ __global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs,
 // =============================================================================================
 constexpr uint32_t kRowPad = kBlockLen + 4;  // LDS row stride: spreads the 128 block rows over the banks
 
-__device__ __forceinline__ void load_advances(const uint32_t *__restrict__ match, uint32_t M, uint32_t p0, uint8_t *adv, uint32_t tid) {
-  for (uint32_t i = tid * 4; i < kSuper; i += 128 * 4) {
-    uint32_t packed = 0x01010101u;
-    if (p0 + i + 3 < M) {
-      const uint4 m = *reinterpret_cast<const uint4 *>(match + p0 + i);
-      const uint32_t l0 = m.x & 0xff, l1 = m.y & 0xff, l2 = m.z & 0xff, l3 = m.w & 0xff;
-      packed = (l0 ? l0 : 1u) | ((l1 ? l1 : 1u) << 8) | ((l2 ? l2 : 1u) << 16) | ((l3 ? l3 : 1u) << 24);
-    } else {
-      for (uint32_t k = 0; k < 4; k++)
-        if (p0 + i + k < M) {
-          const uint32_t l = match[p0 + i + k] & 0xff;
-          packed = (packed & ~(0xffu << (8 * k))) | ((l ? l : 1u) << (8 * k));
-        }
+// adv8[p] = max(1, len[p]) as written by the match kernels; positions at and past M read as 1
+__device__ __forceinline__ void load_advances(const uint8_t *__restrict__ adv8, uint32_t M, uint32_t p0, uint8_t *adv, uint32_t tid) {
+  for (uint32_t i = tid * 16; i < kSuper; i += 128 * 16) {
+    uint4 v = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+    if (p0 + i + 15 < M) {
+      v = *reinterpret_cast<const uint4 *>(adv8 + p0 + i);
+    } else if (p0 + i < M) {
+      uint32_t w[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
+      for (uint32_t k = 0; k < 16 && p0 + i + k < M; k++)
+        w[k >> 2] = (w[k >> 2] & ~(0xffu << (8 * (k & 3)))) | ((uint32_t)adv8[p0 + i + k] << (8 * (k & 3)));
+      v = make_uint4(w[0], w[1], w[2], w[3]);
     }
     const uint32_t row = i / kBlockLen, col = i % kBlockLen;
-    *reinterpret_cast<uint32_t *>(adv + row * kRowPad + col) = packed;
+    uint32_t *d = reinterpret_cast<uint32_t *>(adv + row * kRowPad + col);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   }
 }
 
-// exit[p] for all p of block `row` (thread per block, backwards)
-__device__ __forceinline__ void block_exits(const uint8_t *adv, uint8_t *ex, uint32_t row) {
-  const uint8_t *a = adv + row * kRowPad;
-  uint8_t *e = ex + row * kRowPad;
+// exit[p] for all p of block `row` (thread per block, backwards), in place: exit[i] needs adv[i] and exit[q] for q > i only
+__device__ __forceinline__ void block_exits_in_place(uint8_t *adv, uint32_t row) {
+  uint8_t *e = adv + row * kRowPad;
   for (int i = (int)kBlockLen - 1; i >= 0; i--) {
-    const uint32_t q = (uint32_t)i + a[i];
+    const uint32_t q = (uint32_t)i + e[i];
     e[i] = (uint8_t)(q >= kBlockLen ? q - kBlockLen : e[q]);
   }
 }
 
 __global__ __launch_bounds__(128) void k_parse_exits(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                      const uint32_t *__restrict__ sb_first, uint32_t n,
-                                                     const uint32_t *__restrict__ match, uint8_t *__restrict__ sx) {
-  __shared__ __attribute__((aligned(16))) uint8_t adv[kBlocksPerSuper * kRowPad];
+                                                     const uint8_t *__restrict__ adv8, uint8_t *__restrict__ sx) {
   __shared__ __attribute__((aligned(16))) uint8_t ex[kBlocksPerSuper * kRowPad];
   const uint32_t sb = blockIdx.x, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   const uint32_t M = st[img].M;
   const uint32_t p0 = (sb - sb_first[img]) * kSuper;
   if (p0 >= M) return;
-  load_advances(match + imgs[img].pos0, M, p0, adv, tid);
+  load_advances(adv8 + imgs[img].pos0, M, p0, ex, tid);
   __syncthreads();
-  block_exits(adv, ex, tid);
+  block_exits_in_place(ex, tid);
   __syncthreads();
   uint32_t e = tid;
   for (uint32_t r = 0; r < kBlocksPerSuper; r++) e = ex[r * kRowPad + e];
@@ -528,23 +529,24 @@ __global__ __launch_bounds__(256) void k_parse_chain(const EncState *__restrict_
 
 __global__ __launch_bounds__(128) void k_parse_mark(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                     const uint32_t *__restrict__ sb_first, uint32_t n,
-                                                    const uint32_t *__restrict__ match, const uint8_t *__restrict__ entry,
+                                                    const uint8_t *__restrict__ adv8, const uint8_t *__restrict__ entry,
                                                     uint32_t *__restrict__ flags) {
-  __shared__ __attribute__((aligned(16))) uint8_t adv[kBlocksPerSuper * kRowPad];
-  __shared__ __attribute__((aligned(16))) uint8_t ex[kBlocksPerSuper * kRowPad];
+  __shared__ __attribute__((aligned(16))) uint8_t adv[kBlocksPerSuper * kRowPad];  // exits first, then the advances again
   __shared__ uint8_t ent[kBlocksPerSuper];
   const uint32_t sb = blockIdx.x, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   const uint32_t M = st[img].M;
   const uint32_t p0 = (sb - sb_first[img]) * kSuper;
   if (p0 >= M) return;
-  load_advances(match + imgs[img].pos0, M, p0, adv, tid);
+  load_advances(adv8 + imgs[img].pos0, M, p0, adv, tid);
   __syncthreads();
-  block_exits(adv, ex, tid);
+  block_exits_in_place(adv, tid);
   __syncthreads();
   if (tid == 0) {
     uint32_t e = entry[sb];
-    for (uint32_t r = 0; r < kBlocksPerSuper; r++) { ent[r] = (uint8_t)e; e = ex[r * kRowPad + e]; }
+    for (uint32_t r = 0; r < kBlocksPerSuper; r++) { ent[r] = (uint8_t)e; e = adv[r * kRowPad + e]; }
   }
+  __syncthreads();
+  load_advances(adv8 + imgs[img].pos0, M, p0, adv, tid);  // the same 16 KiB again, from cache
   __syncthreads();
   unsigned long long lo = 0, hi = 0;  // token starts of this thread's block
   const uint32_t bstart = p0 + tid * kBlockLen;
@@ -634,23 +636,71 @@ struct HeaderShared {
   CodeTables tables;
   uint32_t histo[kNumCodes * kCodeStride];
   uint32_t palette[kMaxPalette];
+  HuffScratch huff[3];  // waves 1..3; wave 0 uses sub.desc.huff
+  int rc[kNumCodes];
 };
 
-__global__ __launch_bounds__(64) void k_entropy_header(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
-                                                       const uint32_t *__restrict__ histo, CodeTables *__restrict__ tables,
-                                                       uint8_t *__restrict__ out) {
+// The used symbols' weights in symbol order and their ids sorted by (weight, id), by the whole wave
+// (what huffman_lengths otherwise does with a serial insertion sort).  Returns the number of used symbols.
+__device__ __forceinline__ int wave_prepare_leaves(const uint32_t *h, int n, HuffScratch &hs, uint32_t lane) {
+  uint32_t count = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + (int)lane;
+    const uint32_t w = i < n ? h[i] : 0u;
+    const uint64_t mask = __ballot(w != 0);
+    if (w) hs.wt[count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = w;
+    count += (uint32_t)__popcll(mask);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i = lane; i < count; i += 64) {
+    const uint32_t wi = hs.wt[i];
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < count; j++) {
+      const uint32_t wj = hs.wt[j];
+      r += (wj < wi || (wj == wi && j < i)) ? 1u : 0u;
+    }
+    hs.ord[r] = (uint16_t)i;
+  }
+  __builtin_amdgcn_wave_barrier();
+  return (int)count;
+}
+
+// Four waves: green, red, blue and alpha codes are built side by side (wave 0 then adds the distance
+// code); the sort of each is done by its wave, the joining of the tree by the wave's first lane.
+// Then one lane writes the prefix and the five code descriptions, which are sequential in the stream.
+__global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
+                                                        const uint32_t *__restrict__ histo, CodeTables *__restrict__ tables,
+                                                        uint8_t *__restrict__ out) {
   __shared__ HeaderShared sh;
-  const uint32_t img = blockIdx.x, tid = threadIdx.x;
+  const uint32_t img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const EncImage im = imgs[img];
   const uint32_t *g = histo + (size_t)img * kNumCodes * kCodeStride;
-  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 64) sh.histo[i] = g[i];
-  for (uint32_t i = tid; i < kMaxPalette; i += 64) sh.palette[i] = st[img].palette[i];
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) sh.histo[i] = g[i];
+  for (uint32_t i = tid; i < kMaxPalette; i += 256) sh.palette[i] = st[img].palette[i];
+  __syncthreads();
+  HuffScratch &hs = wave == 0 ? sh.sub.desc.huff : sh.huff[wave - 1];
+  for (uint32_t c = wave; c < (uint32_t)kNumCodes; c += 4) {
+    const int nsym = alphabet_size((int)c);
+    const uint32_t *h = sh.histo + c * kCodeStride;
+    uint8_t *len = sh.tables.len + c * kCodeStride;
+    const int used = wave_prepare_leaves(h, nsym, hs, lane);
+    if (lane == 0) {
+      const int u = huffman_lengths(h, nsym, kMaxCodeLen, len, hs, used);
+      sh.rc[c] = u;
+      if (u >= 0) {
+        sh.tables.used[c] = (uint32_t)u;
+        canonical_reversed_codes(len, nsym, sh.tables.code + c * kCodeStride);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
   __syncthreads();
   if (tid == 0) {
     BitSink bw;
     bw.init(reinterpret_cast<uint32_t *>(out + im.out_off));
     int rc = write_stream_prefix(bw, im.w, im.h, sh.palette, st[img].ncolors, sh.sub);
-    if (rc == 0) rc = build_and_write_codes(bw, sh.histo, sh.tables, sh.sub.desc);
+    for (int c = 0; c < kNumCodes && rc == 0; c++)  // vp8l.h:536-540
+      rc = sh.rc[c] < 0 ? sh.rc[c] : write_code_desc(bw, sh.tables.len + c * kCodeStride, alphabet_size(c), sh.sub.desc);
     bw.flush();
     st[img].hdr_bits = (uint32_t)bw.bits();
     st[img].status = rc;
@@ -658,7 +708,7 @@ __global__ __launch_bounds__(64) void k_entropy_header(const EncImage *__restric
   __syncthreads();
   const uint32_t *src = reinterpret_cast<const uint32_t *>(&sh.tables);
   uint32_t *dst = reinterpret_cast<uint32_t *>(&tables[img]);
-  for (uint32_t i = tid; i < sizeof(CodeTables) / 4; i += 64) dst[i] = src[i];
+  for (uint32_t i = tid; i < sizeof(CodeTables) / 4; i += 256) dst[i] = src[i];
 }
 
 // =============================================================================================
@@ -878,7 +928,14 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
   const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
   if (p0 >= M) return;
   const CodeTables *T = &tables[img];
-  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) tab[i] = make_uint2(T->code[i], T->len[i]);
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride / 4; i += 256) {  // four (code, length) entries at a time
+    const uint4 c4 = reinterpret_cast<const uint4 *>(T->code)[i];
+    const uint32_t l4 = reinterpret_cast<const uint32_t *>(T->len)[i];
+    tab[4 * i + 0] = make_uint2(c4.x, l4 & 0xff);
+    tab[4 * i + 1] = make_uint2(c4.y, (l4 >> 8) & 0xff);
+    tab[4 * i + 2] = make_uint2(c4.z, (l4 >> 16) & 0xff);
+    tab[4 * i + 3] = make_uint2(c4.w, l4 >> 24);
+  }
   bool wr[kNumCodes];
 #pragma unroll
   for (int c = 0; c < kNumCodes; c++) wr[c] = T->used[c] > 1;
@@ -907,7 +964,8 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
   uint32_t *out32 = reinterpret_cast<uint32_t *>(out + im.out_off);
   constexpr long long kWinBits = (long long)kWinWords * 32;
   for (uint64_t wbase = 0; wbase < nwords; wbase += kWinWords) {
-    for (uint32_t i = tid; i < kWinWords + 2; i += 256) stage[i] = 0;
+    const uint64_t cntw = nwords - wbase < kWinWords ? nwords - wbase : kWinWords;
+    for (uint32_t i = tid; i < cntw + 2; i += 256) stage[i] = 0;
     __syncthreads();
     const long long rel = (long long)my_bit - (long long)((first_word + wbase) << 5);
     if (mybits && rel + (long long)mybits > 0 && rel < kWinBits) {
@@ -920,7 +978,6 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
       }
     }
     __syncthreads();
-    const uint64_t cntw = nwords - wbase < kWinWords ? nwords - wbase : kWinWords;
     for (uint32_t i = tid; i < cntw; i += 256) {
       const uint64_t gw = first_word + wbase + i;
       // a word is shared with the neighbouring unit (or the header) when a unit boundary falls inside it
@@ -995,7 +1052,7 @@ struct vp8l_encoder {
   std::mutex mu;
   // workspace (grown on demand)
   DeviceBuffer d_imgs, d_state, d_sbfirst, d_gsets, d_pix, d_match, d_flags, d_histo, d_tables, d_sx, d_entry,
-      d_unit_bits, d_unit_off, d_dense, d_group_bits;
+      d_unit_bits, d_unit_off, d_dense, d_group_bits, d_adv;
   int match_mode = 0;  // 0 = candidate lists with exhaustive fallback, 1 = exhaustive only
   // last batch
   std::vector<EncImage> imgs;
@@ -1033,7 +1090,7 @@ extern "C" void vp8l_encoder_destroy(vp8l_encoder *e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   DeviceBuffer *bufs[] = {&e->d_imgs, &e->d_state, &e->d_sbfirst, &e->d_gsets, &e->d_pix, &e->d_match, &e->d_flags,
-                          &e->d_histo, &e->d_tables, &e->d_sx, &e->d_entry, &e->d_unit_bits, &e->d_unit_off, &e->d_dense, &e->d_group_bits};
+                          &e->d_histo, &e->d_tables, &e->d_sx, &e->d_entry, &e->d_unit_bits, &e->d_unit_off, &e->d_dense, &e->d_group_bits, &e->d_adv};
   for (auto *b : bufs) b->release();
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -1094,7 +1151,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
             e->d_histo.reserve((size_t)nl * kNumCodes * kCodeStride * 4) && e->d_tables.reserve((size_t)nl * sizeof(CodeTables)) &&
             e->d_sx.reserve(sb_total * kBlockLen) && e->d_entry.reserve(sb_total) &&
             e->d_unit_bits.reserve(nunits * 4) && e->d_unit_off.reserve(nunits * 8) &&
-            e->d_dense.reserve(sb_total * (kSuper / kLzTile)) && e->d_group_bits.reserve(npos / 16 * 2);
+            e->d_dense.reserve(sb_total * (kSuper / kLzTile)) && e->d_group_bits.reserve(npos / 16 * 2) && e->d_adv.reserve(npos);
   if (!ok) return VP8L_ERR_NO_MEMORY;
 
   hipStream_t s = e->stream;
@@ -1113,6 +1170,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   auto *uoff = e->d_unit_off.as<uint64_t>();
   auto *dense = e->d_dense.as<uint8_t>();
   auto *gbits = e->d_group_bits.as<uint16_t>();
+  auto *adv8 = e->d_adv.as<uint8_t>();
 
   bool h = true;
   h = h && hip_ok(hipMemcpyAsync(imgs, e->imgs.data(), nl * sizeof(EncImage), hipMemcpyHostToDevice, s), "upload images");
@@ -1131,17 +1189,17 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix);
   (void)hipEventRecord(e->ev[2], s);
   if (e->match_mode == 0)
-    hipLaunchKernelGGL(k_lz77_sparse, dim3(gsb * (kSuper / kSpTile)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, dense);
-  hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match,
+    hipLaunchKernelGGL(k_lz77_sparse, dim3(gsb * (kSuper / kSpTile)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, adv8, dense);
+  hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, adv8,
                      e->match_mode == 0 ? dense : (const uint8_t *)nullptr);
   (void)hipEventRecord(e->ev[3], s);
-  hipLaunchKernelGGL(k_parse_exits, dim3(gsb), dim3(128), 0, s, imgs, st, sbf, nl, match, sx);
+  hipLaunchKernelGGL(k_parse_exits, dim3(gsb), dim3(128), 0, s, imgs, st, sbf, nl, adv8, sx);
   hipLaunchKernelGGL(k_parse_chain, dim3(nl), dim3(256), 0, s, st, sbf, sx, entry);
-  hipLaunchKernelGGL(k_parse_mark, dim3(gsb), dim3(128), 0, s, imgs, st, sbf, nl, match, entry, flags);
+  hipLaunchKernelGGL(k_parse_mark, dim3(gsb), dim3(128), 0, s, imgs, st, sbf, nl, adv8, entry, flags);
   (void)hipEventRecord(e->ev[4], s);
   hipLaunchKernelGGL(k_histogram, dim3(gsb), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, histo);
   (void)hipEventRecord(e->ev[5], s);
-  hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(64), 0, s, imgs, st, histo, tables, d_out);
+  hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, imgs, st, histo, tables, d_out);
   (void)hipEventRecord(e->ev[6], s);
   hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, gbits, ubits);
   hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, imgs, st, sbf, ubits, uoff, d_out);
