@@ -331,6 +331,13 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
 // exceeds a work budget and is handed to the exhaustive kernel (k_lz77) through `dense_tile`.
 // Both kernels produce identical results; only the time differs.
 // =============================================================================================
+// Distance code of a distance <= 1024.  In an image wider than 1024 + 8 pixels such a distance stays in the
+// row (dy = 0, dx = distance), so only dx <= 8 has a short code (lz77.cpp:104-112).
+__device__ __forceinline__ uint32_t dist_code_of(uint32_t xsize, uint32_t xinv, uint32_t dist) {
+  if (xsize > kWindow + 8) return dist <= 8 ? dist_xy_to_code(xsize, dist, 0, dist) : dist + 120;
+  return dist_to_code_inv(xsize, xinv, dist);
+}
+
 constexpr uint32_t kSpTile = 1024;                   // positions per workgroup
 constexpr uint32_t kSpPosBits = 11;                  // sources of a tile: the 1024 before it and the tile itself
 constexpr uint32_t kSpSources = 1u << kSpPosBits;
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
                                                      const uint32_t *__restrict__ sb_first, uint32_t n,
                                                      const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                                      uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
-  __shared__ uint32_t px[kSpSources + kMaxLen];
+  __shared__ __attribute__((aligned(16))) uint32_t px[kSpSources + kMaxLen];
   __shared__ uint32_t cursor[kSpBuckets];  // counts, then insert positions; after the scatter cursor[h] = end of bucket h
   __shared__ uint32_t items[kSpSources];   // (low bits of the mixed pixel) << 11 | index in px
   __shared__ uint32_t wsum[4];
@@ -363,10 +370,17 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
   const uint32_t *data = pix + pos0;
   for (uint32_t i = tid; i < kSpBuckets; i += 256) cursor[i] = 0;
   if (tid == 0) s_abort = 0;
-  for (uint32_t i = tid; i < hi - lo; i += 256) px[i] = data[lo + i];
+  // lo is a multiple of 4 (a and kWindow are) and the pixel array has readable slack past M: 16-byte loads
+  for (uint32_t i = tid * 4; i < hi - lo; i += 1024) *reinterpret_cast<uint4 *>(&px[i]) = *reinterpret_cast<const uint4 *>(data + lo + i);
   __syncthreads();
   const uint32_t nsrc = b - lo;  // pixels lo..b-1 can be sources
-  for (uint32_t i = tid; i < nsrc; i += 256) atomicAdd(&cursor[(px[i] * kSpMul) >> (32 - kSpPosBits)], 1u);
+  uint32_t mixed[kSpSources / 256];  // this thread's sources tid, tid+256, ...: pixel * kSpMul
+#pragma unroll
+  for (uint32_t k = 0; k < kSpSources / 256; k++) {
+    const uint32_t i = k * 256 + tid;
+    mixed[k] = px[i] * kSpMul;  // in bounds: px has kSpSources + kMaxLen entries
+    if (i < nsrc) atomicAdd(&cursor[mixed[k] >> (32 - kSpPosBits)], 1u);
+  }
   __syncthreads();
   // exclusive scan of the bucket counts (8 per thread)
   uint32_t c[8], sum = 0, mx = 0;
@@ -383,9 +397,10 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
 #pragma unroll
   for (int k = 0; k < 8; k++) { cursor[tid * 8 + k] = run; run += c[k]; }
   __syncthreads();
-  for (uint32_t i = tid; i < nsrc; i += 256) {
-    const uint32_t mixed = px[i] * kSpMul;
-    items[atomicAdd(&cursor[mixed >> (32 - kSpPosBits)], 1u)] = (mixed << kSpTagShift) | i;
+#pragma unroll
+  for (uint32_t k = 0; k < kSpSources / 256; k++) {
+    const uint32_t i = k * 256 + tid;
+    if (i < nsrc) items[atomicAdd(&cursor[mixed[k] >> (32 - kSpPosBits)], 1u)] = (mixed[k] << kSpTagShift) | i;
   }
   __syncthreads();
   // every thread: positions a+tid, a+tid+256, ...
@@ -398,7 +413,7 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
     uint32_t key = 0;
     if (p < b && !over) {
       const uint32_t ip = p - lo;
-      const uint32_t mixed = px[ip] * kSpMul, h = mixed >> (32 - kSpPosBits), tag = mixed << kSpTagShift;
+      const uint32_t mx = px[ip] * kSpMul, h = mx >> (32 - kSpPosBits), tag = mx << kSpTagShift;
       const uint32_t end = cursor[h], beg = h ? cursor[h - 1] : 0u;
       const uint32_t rem = M - p < kMaxLen ? M - p : kMaxLen;
       spent += end - beg;
@@ -421,7 +436,7 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
       if (spent > kSpBudget) over = true;
       if (p == M - 1) key = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
     }
-    out[k] = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_to_code_inv(xsize, xinv, key & 2047u) << 19)) : 0u;
+    out[k] = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_code_of(xsize, xinv, key & 2047u) << 19)) : 0u;
   }
   if (over) s_abort = 1;
   __syncthreads();
