@@ -2,7 +2,8 @@
 
 Both are checked per position against the oracle's best match (lz77.h:36-100 restated), on content
 that keeps tiles on the candidate-list path, content that forces the fallback, and mixtures that
-switch inside one image (tile = 2048 coded positions)."""
+switch inside one image (tile = 2048 coded positions).  Runs of equal pixels, aligned run ends,
+runs cut by the window start and by tile borders are the cases the candidate-list kernel reasons about."""
 import numpy as np
 import pytest
 
@@ -53,8 +54,23 @@ def test_photo_like_stays_on_candidate_lists():
     check(O.gen_image(3, 256, 96, 11), 256, 96, "sparse")
 
 
-def test_flat_needs_exhaustive():
-    check(np.full(300 * 40, 0xFF336699, dtype=np.uint32), 300, 40, "dense")
+def test_flat_and_runs_stay_on_candidate_lists():
+    # equal pixels in a row are one candidate run, however long
+    check(np.full(300 * 40, 0xFF336699, dtype=np.uint32), 300, 40, "sparse")
+    check(O.gen_image(4, 640, 40, 3), 640, 40, "sparse")
+    rng = np.random.default_rng(3)
+    runs = np.repeat(rng.integers(0, 1 << 24, size=900, dtype=np.uint32) | np.uint32(0xFF000000), rng.integers(1, 40, size=900))
+    check(runs[:16000], 16000, 1, "sparse")
+    check(runs[:16000], 125, 128, "sparse")
+
+
+def test_two_colour_noise_needs_exhaustive():
+    rng = np.random.default_rng(4)
+    img = np.where(rng.random(300 * 40) < 0.5, np.uint32(0xFF336699), np.uint32(0xFF000000)).astype(np.uint32)
+    check(img, 300, 40)                      # two colours: palette path, 8 pixels bundled per coded pixel
+    img[-300:] = np.arange(300, dtype=np.uint32) * np.uint32(0x010305) | np.uint32(0xFF000000)  # more than 256 colours
+    dense, total = check(img, 300, 40)
+    assert dense >= total - 1, (dense, total)
     check(O.gen_image(5, 256, 64, 3, 2), 256, 64, None)
 
 
@@ -62,7 +78,8 @@ def test_switch_inside_one_image():
     rng = np.random.default_rng(17)
     w, h = 512, 48                      # 24576 positions = 12 tiles
     img = rng.integers(0, 1 << 24, size=w * h, dtype=np.uint32) | np.uint32(0xFF000000)
-    img[5000:9000] = 0xFF101010         # flat stretch crossing tile borders
+    img[5000:9000] = np.where(rng.random(4000) < 0.5, np.uint32(0xFF101010), np.uint32(0xFF202020))  # noise of two colours across tile borders
+    img[11000:12500] = 0xFF303030        # a flat stretch (one run)
     img[15000:15100] = img[14000:14100]  # long match inside a sparse tile, source in the tile before
     img[20480:20480 + 128] = img[20480 - 1024:20480 - 1024 + 128]  # distance 1024 exactly at a tile start
     check(img, w, h, "mixed")
@@ -98,3 +115,47 @@ def test_periodic_patterns():
 
 def test_graphics_generator():
     check(O.gen_image(4, 640, 64, 9), 640, 64)
+
+
+def test_runs_aligned_and_cut_by_the_window():
+    rng = np.random.default_rng(31)
+    n = 2048 * 4
+    a = rng.integers(0, 1 << 24, size=n, dtype=np.uint32) | np.uint32(0xFF000000)
+    v, u = np.uint32(0xFF010203), np.uint32(0xFF0A0B0C)
+    # a source run of 50, later a run of 20 followed by the same pixels that follow the source run:
+    # the best source is the one whose run remainder is 20 (aligned), not the run start
+    a[1000:1050] = v
+    a[1050:1060] = a[3000:3010]
+    a[1500:1520] = v
+    a[1520:1530] = a[3000:3010]
+    # a run longer than the window: every position inside is cut by the window start
+    a[3500:5200] = u
+    # runs of 128 and more (length cap), and a run that ends exactly at a tile border
+    a[5300:5428] = v
+    a[5500:5700] = v
+    a[6100:6144] = u
+    a[6144:6150] = a[3000:3006]
+    # same value, many short runs with different successors
+    for k in range(30):
+        a[6300 + 40 * k: 6300 + 40 * k + 1 + (k % 7)] = v
+    check(a, n, 1)
+    check(a, 128, n // 128)
+    check(a[:8001], 127, 63)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_run_structures(seed):
+    # few values, geometric run lengths: many equal-valued runs with all sorts of alignments
+    rng = np.random.default_rng(100 + seed)
+    nv = int(rng.choice([2, 3, 5, 17]))
+    vals = rng.integers(0, 1 << 24, size=nv, dtype=np.uint32) | np.uint32(0xFF000000)
+    pieces = []
+    total = 0
+    mean = float(rng.choice([1.5, 4, 20, 150]))
+    while total < 12000:
+        r = int(rng.geometric(1.0 / mean))
+        pieces.append(np.full(r, vals[int(rng.integers(0, nv))], dtype=np.uint32))
+        total += r
+    img = np.concatenate(pieces)[:12000]
+    check(img, 12000, 1)
+    check(img, 100, 120)

@@ -15,6 +15,8 @@
 //   k_bitcount / k_scan / k_emit          token bits              vp8l.h:545-583, bit_writer.h:45-64
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <mutex>
 #include <string>
 #include <vector>
@@ -321,15 +323,22 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
 }
 
 // =============================================================================================
-// Candidate-list form of the same search, for tiles whose window holds few equal pixels (natural
-// images).  The 1024 + 1024 pixels that can be a match source for a tile are bucketed by a hash of
-// the pixel value (counting sort in LDS); a position then looks only at the earlier pixels of its
-// own bucket, keeps those with the same VALUE within 1024 (exactly the distances whose first pixel
-// matches, i.e. every candidate the exhaustive search can score above zero) and extends each by
-// direct comparison.  Work is proportional to the number of equal pairs and their match lengths,
-// so a tile with much duplicate content (flat colour, fine periodic patterns) is abandoned when it
-// exceeds a work budget and is handed to the exhaustive kernel (k_lz77) through `dense_tile`.
-// Both kernels produce identical results; only the time differs.
+// Candidate-list form of the same search, for tiles whose window does not hold too many scattered
+// equal pixels (natural images, graphics, flat areas).  Exhaustive search scores every distance
+// whose first pixel matches; most of those cannot win:
+//   * Let p start a run of F equal pixels, and let q-1 and q be two sources of the same value next to
+//     each other (both within the 1024 before p).  With R(q) = length of the run of equal pixels
+//     starting at q, the match from q runs min(R(q), F) pixels when R(q) != F, and on into whatever
+//     follows when R(q) == F.  Unless R(q) == F the match from q-1 is at least as long, and it is
+//     farther, so it wins (lz77.h:68).  Per run of equal source pixels that leaves two candidates:
+//     its first pixel inside the window, and the one whose run remainder equals F ("aligned").
+//   * Lengths are capped at 128, so for F >= 128 only the first pixel is needed.
+// The first pixels of the source runs are bucketed by a hash of the pixel value (counting sort in
+// LDS; the hash is a bijection split into bucket and tag, so bucket + tag equality is value equality).
+// A position looks at its bucket, adds the run that is cut by the window start, and extends each
+// candidate run by run (both sides advance by min of their run remainders).  Work is proportional
+// to the number of equal-valued runs; a tile that exceeds a work budget (e.g. two-colour noise)
+// is handed to the exhaustive kernel (k_lz77) through `dense_tile`.  Both give identical results.
 // =============================================================================================
 // Distance code of a distance <= 1024.  In an image wider than 1024 + 8 pixels such a distance stays in the
 // row (dy = 0, dx = distance), so only dx <= 8 has a short code (lz77.cpp:104-112).
@@ -347,17 +356,21 @@ constexpr uint32_t kSpMul = 0x9E3779B1u;             // odd: x -> x * kSpMul is 
                                                      // same bucket + same tag <=> same pixel value
 constexpr uint32_t kSpMaxBucket = 192;   // a bucket this full means heavy duplication: not a sparse tile
 constexpr uint32_t kSpBudget = 700;      // candidate tests + extension steps one thread may spend (4 positions)
+constexpr uint32_t kSpSeg = 9;           // window pixels per thread in the run-length pass (256 * 9 >= window)
 static_assert(kSpSources == kWindow + kSpTile, "entry layout");
+static_assert(256 * kSpSeg >= kSpSources + kMaxLen, "run-length pass covers the window");
 
 __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                      const uint32_t *__restrict__ sb_first, uint32_t n,
                                                      const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                                      uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
-  __shared__ __attribute__((aligned(16))) uint32_t px[kSpSources + kMaxLen];
+  __shared__ __attribute__((aligned(16))) uint32_t px[256 * kSpSeg + 4];
+  __shared__ uint16_t runlen[kSpSources + kMaxLen];  // pixels equal to this one from here on (within the window)
   __shared__ uint32_t cursor[kSpBuckets];  // counts, then insert positions; after the scatter cursor[h] = end of bucket h
   __shared__ uint32_t items[kSpSources];   // (low bits of the mixed pixel) << 11 | index in px
   __shared__ uint32_t wsum[4];
-  __shared__ uint32_t s_abort;
+  __shared__ uint32_t wmin[4];
+  __shared__ uint32_t s_abort, s_inside;
   constexpr uint32_t kPerSuper = kSuper / kSpTile;
   const uint32_t tile = blockIdx.x, sb = tile / kPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   const uint32_t M = st[img].M, xsize = st[img].xsize, xinv = st[img].xinv;
@@ -366,27 +379,75 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
   const uint32_t b = a + kSpTile < M ? a + kSpTile : M;
   const uint32_t lo = a > kWindow ? a - kWindow : 0;              // first possible source
   const uint32_t hi = b + kMaxLen - 1 < M ? b + kMaxLen - 1 : M;  // one past the last pixel an extension may read
+  const uint32_t W = hi - lo;
   const uint64_t pos0 = imgs[img].pos0;
   const uint32_t *data = pix + pos0;
+  const uint32_t lane = tid & 63, wave = tid >> 6;
   for (uint32_t i = tid; i < kSpBuckets; i += 256) cursor[i] = 0;
-  if (tid == 0) s_abort = 0;
+  if (tid == 0) { s_abort = 0; s_inside = 0; }
   // lo is a multiple of 4 (a and kWindow are) and the pixel array has readable slack past M: 16-byte loads
-  for (uint32_t i = tid * 4; i < hi - lo; i += 1024) *reinterpret_cast<uint4 *>(&px[i]) = *reinterpret_cast<const uint4 *>(data + lo + i);
+  for (uint32_t i = tid * 4; i < W; i += 1024) *reinterpret_cast<uint4 *>(&px[i]) = *reinterpret_cast<const uint4 *>(data + lo + i);
   __syncthreads();
   const uint32_t nsrc = b - lo;  // pixels lo..b-1 can be sources
   uint32_t mixed[kSpSources / 256];  // this thread's sources tid, tid+256, ...: pixel * kSpMul
+  uint32_t first_of_run = 0;         // bit k: source k*256+tid starts a run (or the window)
+  uint32_t valid = 0;                // bit k: source k*256+tid exists
 #pragma unroll
   for (uint32_t k = 0; k < kSpSources / 256; k++) {
     const uint32_t i = k * 256 + tid;
     mixed[k] = px[i] * kSpMul;  // in bounds: px has kSpSources + kMaxLen entries
-    if (i < nsrc) atomicAdd(&cursor[mixed[k] >> (32 - kSpPosBits)], 1u);
+    if (i < nsrc) {
+      valid |= 1u << k;
+      if (i == 0 || px[i - 1] != px[i]) first_of_run |= 1u << k;
+    }
   }
+  // Hardly any equal neighbours (natural images): every pixel is treated as a run of one, which is the
+  // same search without the run bookkeeping.
+  {
+    const uint32_t inside = wave_sum_u32((uint32_t)__popc(valid & ~first_of_run));
+    if (lane == 0 && inside) atomicAdd(&s_inside, inside);
+  }
+  __syncthreads();
+  const bool plain = s_inside * 16 < nsrc;
+  if (plain) first_of_run = valid;
+  if (!plain) {
+    // ---- run lengths: a run ends at j when px[j+1] differs or j is the last pixel of the window
+    const uint32_t s0 = tid * kSpSeg;
+    uint32_t v[kSpSeg + 1];
+#pragma unroll
+    for (uint32_t j = 0; j <= kSpSeg; j++) v[j] = px[s0 + j];  // px is padded to 256 * kSpSeg + 1 entries
+    uint32_t ends = 0;  // bit j: a run ends at s0 + j
+#pragma unroll
+    for (uint32_t j = 0; j < kSpSeg; j++)
+      if (s0 + j < W && (s0 + j == W - 1 || v[j] != v[j + 1])) ends |= 1u << j;
+    const uint32_t firstb = ends ? s0 + (uint32_t)__builtin_ctz(ends) : 0xffffu;
+    // nearest run end in a later segment: suffix minimum over the threads
+    uint32_t m = firstb;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t other = (uint32_t)__shfl_down((int)m, o, 64);
+      if (lane + (uint32_t)o < 64) m = other < m ? other : m;
+    }
+    if (lane == 0) wmin[wave] = m;
+    uint32_t after = (uint32_t)__shfl_down((int)m, 1, 64);
+    if (lane == 63) after = 0xffffu;
+    __syncthreads();
+    for (uint32_t w = wave + 1; w < 4; w++) after = wmin[w] < after ? wmin[w] : after;
+    uint32_t end = after;
+#pragma unroll
+    for (int j = (int)kSpSeg - 1; j >= 0; j--) {
+      if ((ends >> j) & 1u) end = s0 + (uint32_t)j;
+      if (s0 + (uint32_t)j < W) runlen[s0 + j] = (uint16_t)(end - (s0 + j) + 1);
+    }
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < kSpSources / 256; k++)
+    if ((first_of_run >> k) & 1u) atomicAdd(&cursor[mixed[k] >> (32 - kSpPosBits)], 1u);
   __syncthreads();
   // exclusive scan of the bucket counts (8 per thread)
   uint32_t c[8], sum = 0, mx = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) { c[k] = cursor[tid * 8 + k]; sum += c[k]; mx = c[k] > mx ? c[k] : mx; }
-  const uint32_t lane = tid & 63, wave = tid >> 6;
   const uint32_t incl = wave_incl_scan_u32(sum, (int)lane);
   if (lane == 63) wsum[wave] = incl;
   if (mx > kSpMaxBucket) s_abort = 1;
@@ -400,44 +461,72 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
 #pragma unroll
   for (uint32_t k = 0; k < kSpSources / 256; k++) {
     const uint32_t i = k * 256 + tid;
-    if (i < nsrc) items[atomicAdd(&cursor[mixed[k] >> (32 - kSpPosBits)], 1u)] = (mixed[k] << kSpTagShift) | i;
+    if ((first_of_run >> k) & 1u) items[atomicAdd(&cursor[mixed[k] >> (32 - kSpPosBits)], 1u)] = (mixed[k] << kSpTagShift) | i;
   }
   __syncthreads();
   // every thread: positions a+tid, a+tid+256, ...
   uint32_t out[kSpTile / 256];
   uint32_t spent = 0;
   bool over = false;
+  auto search = [&](auto plain_c) {
+  constexpr bool kPlain = decltype(plain_c)::value;
 #pragma unroll 1
   for (uint32_t k = 0; k < kSpTile / 256; k++) {
     const uint32_t p = a + k * 256 + tid;
-    uint32_t key = 0;
+    uint32_t key = 0;  // best so far: length << 11 | distance
     if (p < b && !over) {
-      const uint32_t ip = p - lo;
-      const uint32_t mx = px[ip] * kSpMul, h = mx >> (32 - kSpPosBits), tag = mx << kSpTagShift;
+      const uint32_t ip = p - lo, x = px[ip];
+      const uint32_t mxd = x * kSpMul, h = mxd >> (32 - kSpPosBits), tag = mxd << kSpTagShift;
       const uint32_t end = cursor[h], beg = h ? cursor[h - 1] : 0u;
       const uint32_t rem = M - p < kMaxLen ? M - p : kMaxLen;
-      spent += end - beg;
+      const uint32_t F = kPlain ? 1u : runlen[ip];         // >= 128 means "at least 128"
+      const uint32_t wlo = ip > kWindow ? ip - kWindow : 0u;  // farthest source of p
+      // scores the source at index q (same value as p, wlo <= q < ip)
+      auto candidate = [&](uint32_t q) {
+        const uint32_t d = ip - q;
+        const uint32_t maxl = d < rem ? d : rem;  // no overlap with the source, at most 128, inside the image
+        // what it must reach to replace the best so far: longer, or as long and farther (lz77.h:68)
+        const uint32_t need = (key >> 11) + (d > (key & 2047u) ? 0u : 1u);
+        if (maxl < need) return;
+        if (need > 1 && px[q + need - 1] != px[ip + need - 1]) return;
+        uint32_t l;
+        if (kPlain) {
+          l = 1;
+          while (l < maxl && px[q + l] == px[ip + l]) l++;
+          spent += l;
+        } else {
+          l = 0;
+          do {  // both sides advance by whole runs
+            const uint32_t rq = runlen[q + l], rp = runlen[ip + l];
+            l += rq < rp ? rq : rp;
+            spent++;
+          } while (l < maxl && px[q + l] == px[ip + l]);
+          l = l < maxl ? l : maxl;
+        }
+        if (l >= need) key = (l << 11) | d;
+      };
+      // a source run and, when it ends before p and is longer than p's run, the source aligned with the end of p's run
+      auto source_run = [&](uint32_t s) {
+        candidate(s);
+        if (kPlain) return;
+        const uint32_t r = runlen[s];
+        if (F < kMaxLen && r > F && s + r <= ip) candidate(s + r - F);
+      };
+      if (!kPlain && wlo > 0 && px[wlo] == x && px[wlo - 1] == x) source_run(wlo);  // the run that the window start cuts
       for (uint32_t i = beg; i < end; i++) {
         const uint32_t it = items[i];
-        const uint32_t d = ip - (it & (kSpSources - 1));
-        if ((it ^ tag) >= kSpSources || d - 1 >= kWindow) continue;  // another value, or not one of the 1024 before p
-        const uint32_t iq = ip - d;
-        const uint32_t maxl = d < rem ? d : rem;  // no overlap with the source, at most 128, inside the image
-        // what this candidate must reach to replace the best so far: longer, or as long and farther (lz77.h:68)
-        const uint32_t need = (key >> 11) + (d > (key & 2047u) ? 0u : 1u);
-        if (maxl < need) continue;
-        if (need > 1 && px[iq + need - 1] != px[ip + need - 1]) continue;
-        uint32_t l = 1;
-        while (l < maxl && px[iq + l] == px[ip + l]) l++;
-        spent += l;
-        if (l < need) continue;
-        key = (l << 11) | d;
+        const uint32_t s = it & (kSpSources - 1);
+        spent++;
+        if ((it ^ tag) >= kSpSources || s >= ip || s < wlo) continue;  // another value, or not one of the 1024 before p
+        source_run(s);
       }
       if (spent > kSpBudget) over = true;
       if (p == M - 1) key = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
     }
     out[k] = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_code_of(xsize, xinv, key & 2047u) << 19)) : 0u;
   }
+  };
+  if (plain) search(std::true_type{}); else search(std::false_type{});
   if (over) s_abort = 1;
   __syncthreads();
   if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
