@@ -116,7 +116,8 @@ int vp8l_decoder_decode_device(vp8l_decoder *dec, size_t n, const uint8_t *const
 
 /* Seconds spent in the device part of the last call on the context (HIP events on the
  * context's stream), and per-kernel-stage seconds for the encoder
- * (stage order: palette, transform, match, parse, histogram, header, bitcount+scan, emit). */
+ * (stage order: palette, transform, match, parse, histogram, header, bitcount+scan, emit; a ninth
+ * value is the part of "match" spent in the exhaustive fallback kernel). */
 double vp8l_encoder_last_device_seconds(const vp8l_encoder *enc);
 int vp8l_encoder_last_stage_seconds(const vp8l_encoder *enc, double *seconds, int cap);
 double vp8l_decoder_last_device_seconds(const vp8l_decoder *dec);

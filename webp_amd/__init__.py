@@ -28,7 +28,8 @@ STATUS_NAMES = {
     -10: "BadArgument", -11: "Workspace",
 }
 STAGE_RESIDUAL, STAGE_MATCH, STAGE_HISTO, STAGE_CODELEN, STAGE_INFO = range(5)
-ENCODE_STAGES = ("palette", "transform", "match", "parse", "histogram", "header", "bitcount_scan", "emit")
+ENCODE_STAGES = ("palette", "transform", "match", "parse", "histogram", "header", "bitcount_scan", "emit",
+                 "match_fallback")  # the last one is the part of "match" spent in the exhaustive kernel
 
 
 class Vp8lError(RuntimeError):
@@ -267,8 +268,8 @@ class Encoder:
         return int(dense), int(total.value)
 
     def last_stage_seconds(self):
-        buf = (C.c_double * 8)()
-        k = lib().vp8l_encoder_last_stage_seconds(self._h, buf, 8)
+        buf = (C.c_double * 9)()
+        k = lib().vp8l_encoder_last_stage_seconds(self._h, buf, 9)
         return dict(zip(ENCODE_STAGES, buf[:k]))
 
 

@@ -361,7 +361,7 @@ static_assert(kSpSources == kWindow + kSpTile, "entry layout");
 static_assert(256 * kSpSeg >= kSpSources + kMaxLen, "run-length pass covers the window");
 
 __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
-                                                     const uint32_t *__restrict__ sb_first, uint32_t n,
+                                                     const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
                                                      const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                                      uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
   __shared__ __attribute__((aligned(16))) uint32_t px[256 * kSpSeg + 4];
@@ -372,7 +372,12 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
   __shared__ uint32_t wmin[4];
   __shared__ uint32_t s_abort, s_inside;
   constexpr uint32_t kPerSuper = kSuper / kSpTile;
-  const uint32_t tile = blockIdx.x, sb = tile / kPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  // Workgroups go round-robin to the 8 XCDs, each with its own L2.  Neighbouring tiles share half of their
+  // window, so every XCD takes one contiguous eighth of the tiles: the overlap is then read from its L2, not twice from HBM.
+  const uint32_t per_xcd = gridDim.x / 8;  // the grid is a multiple of 8
+  const uint32_t tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (tile >= ntiles) return;
+  const uint32_t sb = tile / kPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   const uint32_t M = st[img].M, xsize = st[img].xsize, xinv = st[img].xinv;
   const uint32_t a = (tile - sb_first[img] * kPerSuper) * kSpTile;
   if (a >= M) return;
@@ -1164,7 +1169,7 @@ struct vp8l_encoder {
   std::vector<uint32_t> sb_first;
   uint8_t *last_out = nullptr;
   double last_seconds = 0;
-  double stage_seconds[8] = {};
+  double stage_seconds[9] = {};
 };
 
 extern "C" size_t vp8l_encode_bound(uint32_t w, uint32_t h) {
@@ -1293,7 +1298,9 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix);
   (void)hipEventRecord(e->ev[2], s);
   if (e->match_mode == 0)
-    hipLaunchKernelGGL(k_lz77_sparse, dim3(gsb * (kSuper / kSpTile)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, adv8, dense);
+    hipLaunchKernelGGL(k_lz77_sparse, dim3((gsb * (kSuper / kSpTile) + 7) / 8 * 8), dim3(256), 0, s, imgs, st, sbf, nl,
+                       gsb * (kSuper / kSpTile), pix, match, adv8, dense);
+  (void)hipEventRecord(e->ev[9], s);  // also when the candidate-list kernel is switched off
   hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, adv8,
                      e->match_mode == 0 ? dense : (const uint8_t *)nullptr);
   (void)hipEventRecord(e->ev[3], s);
@@ -1322,6 +1329,9 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
     (void)hipEventElapsedTime(&ms, e->ev[k], e->ev[k + 1]);
     e->stage_seconds[k] = ms * 1e-3;
   }
+  ms = 0;
+  (void)hipEventElapsedTime(&ms, e->ev[9], e->ev[3]);  // the exhaustive kernel alone (part of stage 2)
+  e->stage_seconds[8] = ms * 1e-3;
   e->last_out = d_out;
   for (uint32_t k = 0; k < nl; k++) {
     const size_t i = live[k];
@@ -1408,7 +1418,7 @@ extern "C" long vp8l_encoder_last_dense_tiles(vp8l_encoder *e, long *total_tiles
 
 extern "C" int vp8l_encoder_last_stage_seconds(const vp8l_encoder *e, double *seconds, int cap) {
   if (!e || !seconds) return VP8L_ERR_BAD_ARGUMENT;
-  const int k = cap < 8 ? cap : 8;
+  const int k = cap < 9 ? cap : 9;
   for (int i = 0; i < k; i++) seconds[i] = e->stage_seconds[i];
   return k;
 }
