@@ -305,24 +305,29 @@ VP8L_HD void histo_token(uint32_t *histo, uint32_t pixel, uint32_t len, uint32_t
   }
 }
 
-// WriteEntropyCodedImage for the palette (vp8l.h:477-510, called from :457 with xsize = n, ysize = 1).
+// The pieces of WriteEntropyCodedImage for the palette (vp8l.h:477-510, called from :457 with xsize = n,
+// ysize = 1).  The device computes the matches and the code
+// lengths with many lanes and calls the pieces; write_small_coded_image is the same thing in one go.
+VP8L_HD void small_histogram(const uint32_t *data, int n, SubImageScratch &s) {
+  for (int i = 0; i < kNumCodes * kCodeStride; i++) s.histo[i] = 0;
+  for (int p = 0; p < n; p += s.lz.len[p] ? s.lz.len[p] : 1) histo_token(s.histo, data[p], s.lz.len[p], s.lz.dist[p], (uint32_t)n);
+}
+VP8L_HD void small_write_tokens(BitSink &bw, const uint32_t *data, int n, SubImageScratch &s) {
+  for (int p = 0; p < n; p += s.lz.len[p] ? s.lz.len[p] : 1)
+    emit_token([&](uint32_t v, uint32_t nb) { bw.put(v, nb); }, s.tables, data[p], s.lz.len[p], s.lz.dist[p], (uint32_t)n);
+}
 VP8L_HD int write_small_coded_image(BitSink &bw, const uint32_t *data, int n, SubImageScratch &s) {
   bw.put(0, 1);  // no colour cache
   small_best_matches(data, n, s.lz);
-  for (int i = 0; i < kNumCodes * kCodeStride; i++) s.histo[i] = 0;
-  for (int p = 0; p < n; p += s.lz.len[p] ? s.lz.len[p] : 1) histo_token(s.histo, data[p], s.lz.len[p], s.lz.dist[p], (uint32_t)n);
+  small_histogram(data, n, s);
   const int rc = build_and_write_codes(bw, s.histo, s.tables, s.desc);
   if (rc < 0) return rc;
-  for (int p = 0; p < n; p += s.lz.len[p] ? s.lz.len[p] : 1)
-    emit_token([&](uint32_t v, uint32_t nb) { bw.put(v, nb); }, s.tables, data[p], s.lz.len[p], s.lz.dist[p], (uint32_t)n);
+  small_write_tokens(bw, data, n, s);
   return 0;
 }
 
-// Everything in front of the main image's five code descriptions:
-// write_info (vp8l.h:460-467), the transform (subtract green :417-418, or colour indexing with its
-// delta-coded palette :451-457), "no more transforms" (:609), "no cache", "no meta codes" (:512-513).
-VP8L_HD int write_stream_prefix(BitSink &bw, uint32_t w, uint32_t h, const uint32_t *palette, uint32_t ncolors,
-                                SubImageScratch &s) {
+// Everything in front of the main image's codes (vp8l.h:585-612, WriteTransforms :411-459).
+VP8L_HD void write_stream_head(BitSink &bw, uint32_t w, uint32_t h, uint32_t ncolors) {
   bw.put(0, 32);
   bw.put(0x2f, 8);
   bw.put(w - 1, 14);
@@ -335,14 +340,26 @@ VP8L_HD int write_stream_prefix(BitSink &bw, uint32_t w, uint32_t h, const uint3
   } else {
     bw.put(3, 2);
     bw.put(ncolors - 1, 8);
-    s.delta[0] = palette[0];
-    for (uint32_t i = 1; i < ncolors; i++) s.delta[i] = px_sub(palette[i], palette[i - 1]);  // vp8l.h:455-456
+  }
+}
+VP8L_HD void palette_deltas(const uint32_t *palette, uint32_t ncolors, uint32_t *delta) {  // vp8l.h:455-456
+  delta[0] = palette[0];
+  for (uint32_t i = 1; i < ncolors; i++) delta[i] = px_sub(palette[i], palette[i - 1]);
+}
+VP8L_HD void write_stream_tail(BitSink &bw) {
+  bw.put(0, 1);
+  bw.put(0, 1);
+  bw.put(0, 1);
+}
+VP8L_HD int write_stream_prefix(BitSink &bw, uint32_t w, uint32_t h, const uint32_t *palette, uint32_t ncolors,
+                                SubImageScratch &s) {
+  write_stream_head(bw, w, h, ncolors);
+  if (ncolors) {
+    palette_deltas(palette, ncolors, s.delta);
     const int rc = write_small_coded_image(bw, s.delta, (int)ncolors, s);
     if (rc < 0) return rc;
   }
-  bw.put(0, 1);
-  bw.put(0, 1);
-  bw.put(0, 1);
+  write_stream_tail(bw);
   return 0;
 }
 

@@ -774,40 +774,89 @@ __device__ __forceinline__ int wave_prepare_leaves(const uint32_t *h, int n, Huf
   return (int)count;
 }
 
-// Four waves: green, red, blue and alpha codes are built side by side (wave 0 then adds the distance
-// code); the sort of each is done by its wave, the joining of the tree by the wave's first lane.
-// Then one lane writes the prefix and the five code descriptions, which are sequential in the stream.
-__global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
-                                                        const uint32_t *__restrict__ histo, CodeTables *__restrict__ tables,
-                                                        uint8_t *__restrict__ out) {
-  __shared__ HeaderShared sh;
-  const uint32_t img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const EncImage im = imgs[img];
-  const uint32_t *g = histo + (size_t)img * kNumCodes * kCodeStride;
-  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) sh.histo[i] = g[i];
-  for (uint32_t i = tid; i < kMaxPalette; i += 256) sh.palette[i] = st[img].palette[i];
-  __syncthreads();
-  HuffScratch &hs = wave == 0 ? sh.sub.desc.huff : sh.huff[wave - 1];
+// The five codes of one coded image from its five histograms, by four waves: green, red, blue and alpha side
+// by side (wave 0 then adds the distance code); the sort of each is done by its wave, the joining of the tree
+// by the wave's first lane.  rc[c] < 0: that code failed (TooBigCodeLength).  Ends with a barrier.
+__device__ __forceinline__ void build_codes_4waves(const uint32_t *histo5, CodeTables &t, int *rc, HuffScratch &hs, uint32_t wave,
+                                                   uint32_t lane) {
   for (uint32_t c = wave; c < (uint32_t)kNumCodes; c += 4) {
     const int nsym = alphabet_size((int)c);
-    const uint32_t *h = sh.histo + c * kCodeStride;
-    uint8_t *len = sh.tables.len + c * kCodeStride;
+    const uint32_t *h = histo5 + c * kCodeStride;
+    uint8_t *len = t.len + c * kCodeStride;
     const int used = wave_prepare_leaves(h, nsym, hs, lane);
     if (lane == 0) {
       const int u = huffman_lengths(h, nsym, kMaxCodeLen, len, hs, used);
-      sh.rc[c] = u;
+      rc[c] = u;
       if (u >= 0) {
-        sh.tables.used[c] = (uint32_t)u;
-        canonical_reversed_codes(len, nsym, sh.tables.code + c * kCodeStride);
+        t.used[c] = (uint32_t)u;
+        canonical_reversed_codes(len, nsym, t.code + c * kCodeStride);
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
+}
+
+// Per image: the codes and every bit in front of the first token.  The parts with many independent items
+// (palette matches, sorting) use the workgroup; the bits are written by one lane, in stream order.
+__global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
+                                                        const uint32_t *__restrict__ histo, CodeTables *__restrict__ tables,
+                                                        uint8_t *__restrict__ out) {
+  __shared__ HeaderShared sh;
+  __shared__ BitSink bw;
+  __shared__ int s_rc;
+  const uint32_t img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const EncImage im = imgs[img];
+  const uint32_t ncolors = st[img].ncolors;
+  const uint32_t *g = histo + (size_t)img * kNumCodes * kCodeStride;
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) sh.histo[i] = g[i];
+  for (uint32_t i = tid; i < kMaxPalette; i += 256) sh.palette[i] = st[img].palette[i];
   if (tid == 0) {
-    BitSink bw;
     bw.init(reinterpret_cast<uint32_t *>(out + im.out_off));
-    int rc = write_stream_prefix(bw, im.w, im.h, sh.palette, st[img].ncolors, sh.sub);
+    write_stream_head(bw, im.w, im.h, ncolors);
+    s_rc = 0;
+  }
+  __syncthreads();
+  HuffScratch &hs = wave == 0 ? sh.sub.desc.huff : sh.huff[wave - 1];
+  if (ncolors) {  // the palette as a coded image of ncolors x 1 (vp8l.h:455-457)
+    const int np = (int)ncolors;
+    uint32_t *d = sh.sub.delta;
+    if (tid < ncolors) d[tid] = tid ? px_sub(sh.palette[tid], sh.palette[tid - 1]) : sh.palette[0];
+    __syncthreads();
+    if ((int)tid < np) {  // best match of every position, same rules as small_best_matches
+      const int p = (int)tid;
+      const int rem = np - p < (int)kMaxLen ? np - p : (int)kMaxLen;
+      int best = 0, bestd = 0;
+      const uint32_t x = d[p];
+      for (int dd = 1; dd <= p; dd++) {
+        if (d[p - dd] != x) continue;
+        const int maxl = dd < rem ? dd : rem;
+        int l = 1;
+        while (l < maxl && d[p - dd + l] == d[p + l]) l++;
+        if (l >= best) { best = l; bestd = dd; }  // farthest among equals
+      }
+      if (rem <= 1) best = 0;
+      sh.sub.lz.len[p] = (uint16_t)best;
+      sh.sub.lz.dist[p] = (uint16_t)bestd;
+    }
+    __syncthreads();
+    if (tid == 0) small_histogram(d, np, sh.sub);
+    __syncthreads();
+    build_codes_4waves(sh.sub.histo, sh.sub.tables, sh.rc, hs, wave, lane);
+    if (tid == 0) {
+      bw.put(0, 1);  // no colour cache
+      int rc = 0;
+      for (int c = 0; c < kNumCodes && rc == 0; c++)
+        rc = sh.rc[c] < 0 ? sh.rc[c] : write_code_desc(bw, sh.sub.tables.len + c * kCodeStride, alphabet_size(c), sh.sub.desc);
+      if (rc == 0) small_write_tokens(bw, d, np, sh.sub);
+      s_rc = rc;
+    }
+    __syncthreads();
+  }
+  build_codes_4waves(sh.histo, sh.tables, sh.rc, hs, wave, lane);
+  if (tid == 0) {
+    int rc = s_rc;
+    if (rc == 0) write_stream_tail(bw);
     for (int c = 0; c < kNumCodes && rc == 0; c++)  // vp8l.h:536-540
       rc = sh.rc[c] < 0 ? sh.rc[c] : write_code_desc(bw, sh.tables.len + c * kCodeStride, alphabet_size(c), sh.sub.desc);
     bw.flush();
