@@ -874,23 +874,24 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
 // =============================================================================================
 // A match word holds length (bits 0-7), distance (8-18) and the distance code (19-29).
 // Bits of one token with the code lengths alone (vp8l.h:545-583).
-__device__ __forceinline__ uint32_t token_bit_count(const uint8_t *lens, const bool *wr, uint32_t pixel, uint32_t m) {
+// `lens` has zeros for the codes that are not written (vp8l.h:552-566: a code with at most one used symbol), except
+// the length prefixes, which are always written (vp8l.h:570).
+__device__ __forceinline__ uint32_t token_bit_count(const uint8_t *lens, uint32_t pixel, uint32_t m) {
   const uint32_t len = m & 0xff;
-  if (len == 0) {
-    uint32_t bits = 0;
-    if (wr[kGreen]) bits += lens[kGreen * kCodeStride + ((pixel >> 8) & 0xff)];
-    if (wr[kRed]) bits += lens[kRed * kCodeStride + ((pixel >> 16) & 0xff)];
-    if (wr[kBlue]) bits += lens[kBlue * kCodeStride + (pixel & 0xff)];
-    if (wr[kAlpha]) bits += lens[kAlpha * kCodeStride + (pixel >> 24)];
-    return bits;
-  }
+  if (len == 0)
+    return (uint32_t)lens[kGreen * kCodeStride + ((pixel >> 8) & 0xff)] + lens[kRed * kCodeStride + ((pixel >> 16) & 0xff)] +
+           lens[kBlue * kCodeStride + (pixel & 0xff)] + lens[kAlpha * kCodeStride + (pixel >> 24)];
   uint32_t sym, nb, eb, bits;
   prefix_encode(len, sym, nb, eb);
-  bits = lens[kGreen * kCodeStride + 256 + sym] + nb;  // always written (vp8l.h:570)
+  bits = lens[kGreen * kCodeStride + 256 + sym] + nb;
   prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);
-  bits += nb;
-  if (wr[kDist]) bits += lens[kDist * kCodeStride + sym];
-  return bits;
+  return bits + nb + lens[kDist * kCodeStride + sym];
+}
+
+// index i of the 5 x kCodeStride tables belongs to a code whose symbols are not written
+__device__ __forceinline__ bool code_unwritten(const CodeTables *T, uint32_t i) {
+  const uint32_t c = i / kCodeStride, sym = i % kCodeStride;
+  return T->used[c] <= 1 && !(c == (uint32_t)kGreen && sym >= 256);
 }
 
 // sum over 4 adjacent lanes, valid in the last of them
@@ -913,11 +914,10 @@ __global__ __launch_bounds__(256) void k_bitcount(const EncImage *__restrict__ i
   const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
   if (p0 >= M) return;
   const CodeTables *T = &tables[img];
-  for (uint32_t i = tid; i < kNumCodes * kCodeStride / 4; i += 256)
-    reinterpret_cast<uint32_t *>(lens)[i] = reinterpret_cast<const uint32_t *>(T->len)[i];
-  bool wr[kNumCodes];
-#pragma unroll
-  for (int c = 0; c < kNumCodes; c++) wr[c] = T->used[c] > 1;
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride / 4; i += 256) {  // kCodeStride is a multiple of 4, 256 too
+    const uint32_t l4 = reinterpret_cast<const uint32_t *>(T->len)[i];
+    reinterpret_cast<uint32_t *>(lens)[i] = code_unwritten(T, 4 * i) ? 0u : l4;
+  }
   __syncthreads();
   const uint64_t pos0 = imgs[img].pos0;
   uint32_t total = 0;
@@ -931,10 +931,10 @@ __global__ __launch_bounds__(256) void k_bitcount(const EncImage *__restrict__ i
       const uint4 x4 = *reinterpret_cast<const uint4 *>(pix + pos0 + p);
       uint32_t fl = (flags[(pos0 + p) >> 5] >> ((pos0 + p) & 31)) & 15u;
       if (p + 4 > M) fl &= (1u << (M - p)) - 1u;
-      if (fl & 1u) bits += token_bit_count(lens, wr, x4.x, m4.x);
-      if (fl & 2u) bits += token_bit_count(lens, wr, x4.y, m4.y);
-      if (fl & 4u) bits += token_bit_count(lens, wr, x4.z, m4.z);
-      if (fl & 8u) bits += token_bit_count(lens, wr, x4.w, m4.w);
+      if (fl & 1u) bits += token_bit_count(lens, x4.x, m4.x);
+      if (fl & 2u) bits += token_bit_count(lens, x4.y, m4.y);
+      if (fl & 4u) bits += token_bit_count(lens, x4.z, m4.z);
+      if (fl & 8u) bits += token_bit_count(lens, x4.w, m4.w);
     }
     total += bits;
     const uint32_t g = quad_sum_u32(bits);  // positions p-12 .. p+3: one group
@@ -1031,28 +1031,37 @@ struct RunPut {
   __device__ __forceinline__ void finish() { if (fill) atomicOr(&stage[w], (uint32_t)acc); }
 };
 
+// `tab` has (0, 0) for the codes that are not written.  A token of at most 32 bits (nearly all) goes out in one piece.
 template <class Put>
-__device__ __forceinline__ void emit_token_packed(Put &put, const uint2 *tab, const bool *wr, uint32_t pixel, uint32_t m) {
+__device__ __forceinline__ void emit_token_packed(Put &put, const uint2 *tab, uint32_t pixel, uint32_t m) {
   const uint32_t len = m & 0xff;
+  uint2 e0, e1, e2, e3;  // (bits, count) of the four parts
   if (len == 0) {
-    if (wr[kGreen]) { const uint2 e = tab[kGreen * kCodeStride + ((pixel >> 8) & 0xff)]; put(e.x, e.y); }
-    if (wr[kRed]) { const uint2 e = tab[kRed * kCodeStride + ((pixel >> 16) & 0xff)]; put(e.x, e.y); }
-    if (wr[kBlue]) { const uint2 e = tab[kBlue * kCodeStride + (pixel & 0xff)]; put(e.x, e.y); }
-    if (wr[kAlpha]) { const uint2 e = tab[kAlpha * kCodeStride + (pixel >> 24)]; put(e.x, e.y); }
+    e0 = tab[kGreen * kCodeStride + ((pixel >> 8) & 0xff)];
+    e1 = tab[kRed * kCodeStride + ((pixel >> 16) & 0xff)];
+    e2 = tab[kBlue * kCodeStride + (pixel & 0xff)];
+    e3 = tab[kAlpha * kCodeStride + (pixel >> 24)];
   } else {
     uint32_t sym, nb, eb;
     prefix_encode(len, sym, nb, eb);
-    { const uint2 e = tab[kGreen * kCodeStride + 256 + sym]; put(e.x, e.y); }  // always written (vp8l.h:570)
-    if (nb) put(eb, nb);
+    e0 = tab[kGreen * kCodeStride + 256 + sym];
+    e1 = make_uint2(eb, nb);
     prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);
-    if (wr[kDist]) { const uint2 e = tab[kDist * kCodeStride + sym]; put(e.x, e.y); }
-    if (nb) put(eb, nb);
+    e2 = tab[kDist * kCodeStride + sym];
+    e3 = make_uint2(eb, nb);
+  }
+  const uint32_t n1 = e0.y + e1.y, n2 = n1 + e2.y, n = n2 + e3.y;
+  if (n <= 32) {
+    // a part with no bits has value 0, so a shift count of 32 (taken mod 32) cannot leak anything
+    put(e0.x | (e1.x << (e0.y & 31)) | (e2.x << (n1 & 31)) | (e3.x << (n2 & 31)), n);
+  } else {
+    put(e0.x, e0.y); put(e1.x, e1.y); put(e2.x, e2.y); put(e3.x, e3.y);
   }
 }
 
 // The tokens of 16 consecutive positions, fetched four at a time.
 template <class Put>
-__device__ __forceinline__ void emit_group(Put &put, const uint2 *tab, const bool *wr, const uint32_t *__restrict__ px,
+__device__ __forceinline__ void emit_group(Put &put, const uint2 *tab, const uint32_t *__restrict__ px,
                                            const uint32_t *__restrict__ mt, uint32_t fl) {
   uint4 m4 = *reinterpret_cast<const uint4 *>(mt), p4 = *reinterpret_cast<const uint4 *>(px);
 #pragma unroll 1
@@ -1062,10 +1071,10 @@ __device__ __forceinline__ void emit_group(Put &put, const uint2 *tab, const boo
       m4 = *reinterpret_cast<const uint4 *>(mt + 4 * g + 4);
       p4 = *reinterpret_cast<const uint4 *>(px + 4 * g + 4);
     }
-    if (fl & 1u) emit_token_packed(put, tab, wr, pc.x, mc.x);
-    if (fl & 2u) emit_token_packed(put, tab, wr, pc.y, mc.y);
-    if (fl & 4u) emit_token_packed(put, tab, wr, pc.z, mc.z);
-    if (fl & 8u) emit_token_packed(put, tab, wr, pc.w, mc.w);
+    if (fl & 1u) emit_token_packed(put, tab, pc.x, mc.x);
+    if (fl & 2u) emit_token_packed(put, tab, pc.y, mc.y);
+    if (fl & 4u) emit_token_packed(put, tab, pc.z, mc.z);
+    if (fl & 8u) emit_token_packed(put, tab, pc.w, mc.w);
   }
   put.finish();
 }
@@ -1089,14 +1098,12 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
   for (uint32_t i = tid; i < kNumCodes * kCodeStride / 4; i += 256) {  // four (code, length) entries at a time
     const uint4 c4 = reinterpret_cast<const uint4 *>(T->code)[i];
     const uint32_t l4 = reinterpret_cast<const uint32_t *>(T->len)[i];
-    tab[4 * i + 0] = make_uint2(c4.x, l4 & 0xff);
-    tab[4 * i + 1] = make_uint2(c4.y, (l4 >> 8) & 0xff);
-    tab[4 * i + 2] = make_uint2(c4.z, (l4 >> 16) & 0xff);
-    tab[4 * i + 3] = make_uint2(c4.w, l4 >> 24);
+    const bool off = code_unwritten(T, 4 * i);  // kCodeStride is a multiple of 4: the four entries belong to one code part
+    tab[4 * i + 0] = off ? make_uint2(0, 0) : make_uint2(c4.x, l4 & 0xff);
+    tab[4 * i + 1] = off ? make_uint2(0, 0) : make_uint2(c4.y, (l4 >> 8) & 0xff);
+    tab[4 * i + 2] = off ? make_uint2(0, 0) : make_uint2(c4.z, (l4 >> 16) & 0xff);
+    tab[4 * i + 3] = off ? make_uint2(0, 0) : make_uint2(c4.w, l4 >> 24);
   }
-  bool wr[kNumCodes];
-#pragma unroll
-  for (int c = 0; c < kNumCodes; c++) wr[c] = T->used[c] > 1;
   const EncImage im = imgs[img];
   const uint64_t pos0 = im.pos0;
   // this thread's 16 consecutive positions (the arrays have readable slack past M)
@@ -1129,10 +1136,10 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
     if (mybits && rel + (long long)mybits > 0 && rel < kWinBits) {
       if (rel >= 0 && rel + (long long)mybits <= kWinBits) {
         RunPut put(stage, (uint32_t)rel);
-        emit_group(put, tab, wr, px, mt, fl);
+        emit_group(put, tab, px, mt, fl);
       } else {  // the run crosses a window edge
         StagePut put{stage, rel};
-        emit_group(put, tab, wr, px, mt, fl);
+        emit_group(put, tab, px, mt, fl);
       }
     }
     __syncthreads();
