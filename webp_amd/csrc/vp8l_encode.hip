@@ -675,14 +675,16 @@ __device__ __forceinline__ uint32_t flag_at(const uint32_t *__restrict__ flags, 
 // Histograms (vp8l.h:516-535): LDS-private per block, merged into the image's 5x280 counters.
 // =============================================================================================
 // One count per active lane.  Lanes that all hold the same symbol (an opaque alpha channel, a flat
-// colour plane) would serialise on one LDS address: then one lane adds the number of lanes.
+// colour plane) would serialise on one LDS address: then one lane adds the number of lanes.  Otherwise the
+// lane adds to one of kHistCopies interleaved copies (equal symbols in one wave meet 4 times less often).
+constexpr uint32_t kHistCopies = 4;
 __device__ __forceinline__ void histo_add(uint32_t *h, uint32_t sym) {
   const uint64_t active = __ballot(1);
   const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym);
   if (__ballot(sym == first) == active) {
-    if ((uint32_t)__builtin_ctzll(active) == (threadIdx.x & 63u)) atomicAdd(&h[first], (uint32_t)__popcll(active));
+    if ((uint32_t)__builtin_ctzll(active) == (threadIdx.x & 63u)) atomicAdd(&h[first * kHistCopies], (uint32_t)__popcll(active));
   } else {
-    atomicAdd(&h[sym], 1u);
+    atomicAdd(&h[sym * kHistCopies + (threadIdx.x & (kHistCopies - 1))], 1u);
   }
 }
 
@@ -690,13 +692,13 @@ __global__ __launch_bounds__(256) void k_histogram(const EncImage *__restrict__ 
                                                    const uint32_t *__restrict__ sb_first, uint32_t n,
                                                    const uint32_t *__restrict__ pix, const uint32_t *__restrict__ match,
                                                    const uint32_t *__restrict__ flags, uint32_t *__restrict__ histo) {
-  __shared__ uint32_t h[kNumCodes * kCodeStride];
+  __shared__ __attribute__((aligned(16))) uint32_t h[kNumCodes * kCodeStride * kHistCopies];
   // one superblock per workgroup: the merge into the image's counters (up to 1400 global atomics) is paid once per 16384 positions
   const uint32_t sb = blockIdx.x, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   const uint32_t M = st[img].M;
   const uint32_t p0 = (sb - sb_first[img]) * kSuper;
   if (p0 >= M) return;
-  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) h[i] = 0;
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride * kHistCopies; i += 256) h[i] = 0;
   __syncthreads();
   const uint64_t pos0 = imgs[img].pos0;
   // four consecutive positions per thread, everything loaded before anything is used (the arrays have
@@ -716,23 +718,26 @@ __global__ __launch_bounds__(256) void k_histogram(const EncImage *__restrict__ 
       const uint32_t m = mm[j], len = m & 0xff;
       if (len == 0) {
         const uint32_t px = xx[j];
-        histo_add(&h[kGreen * kCodeStride], (px >> 8) & 0xff);
-        histo_add(&h[kRed * kCodeStride], (px >> 16) & 0xff);
-        histo_add(&h[kBlue * kCodeStride], px & 0xff);
-        histo_add(&h[kAlpha * kCodeStride], px >> 24);
+        histo_add(&h[kGreen * kCodeStride * kHistCopies], (px >> 8) & 0xff);
+        histo_add(&h[kRed * kCodeStride * kHistCopies], (px >> 16) & 0xff);
+        histo_add(&h[kBlue * kCodeStride * kHistCopies], px & 0xff);
+        histo_add(&h[kAlpha * kCodeStride * kHistCopies], px >> 24);
       } else {
         uint32_t sym, nb, eb;
         prefix_encode(len, sym, nb, eb);
-        atomicAdd(&h[kGreen * kCodeStride + 256 + sym], 1u);
+        atomicAdd(&h[(kGreen * kCodeStride + 256 + sym) * kHistCopies + (tid & (kHistCopies - 1))], 1u);
         prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);  // distance code, computed with the match
-        atomicAdd(&h[kDist * kCodeStride + sym], 1u);
+        atomicAdd(&h[(kDist * kCodeStride + sym) * kHistCopies + (tid & (kHistCopies - 1))], 1u);
       }
     }
   }
   __syncthreads();
   uint32_t *g = histo + (size_t)img * kNumCodes * kCodeStride;
-  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256)
-    if (h[i]) atomicAdd(&g[i], h[i]);
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) {
+    const uint4 c = *reinterpret_cast<const uint4 *>(&h[i * kHistCopies]);
+    const uint32_t v = c.x + c.y + c.z + c.w;
+    if (v) atomicAdd(&g[i], v);
+  }
 }
 
 // =============================================================================================
