@@ -347,29 +347,33 @@ __device__ __forceinline__ uint32_t dist_code_of(uint32_t xsize, uint32_t xinv, 
   return dist_to_code_inv(xsize, xinv, dist);
 }
 
-constexpr uint32_t kSpTile = 1024;                   // positions per workgroup
-constexpr uint32_t kSpPosBits = 11;                  // sources of a tile: the 1024 before it and the tile itself
-constexpr uint32_t kSpSources = 1u << kSpPosBits;
+constexpr uint32_t kSpThreads = 512;
+constexpr uint32_t kSpWaves = kSpThreads / 64;
+constexpr uint32_t kSpTile = 2048;                   // positions per workgroup
+constexpr uint32_t kSpSources = kWindow + kSpTile;   // sources of a tile: the 1024 before it and the tile itself
+constexpr uint32_t kSpPosBits = 12;                  // bits of a source index
 constexpr uint32_t kSpBuckets = 1u << kSpPosBits;    // top bits of the mixed pixel select the bucket ...
 constexpr uint32_t kSpTagShift = kSpPosBits;         // ... the remaining low bits are kept with the entry
 constexpr uint32_t kSpMul = 0x9E3779B1u;             // odd: x -> x * kSpMul is a bijection on 32 bits, so
                                                      // same bucket + same tag <=> same pixel value
 constexpr uint32_t kSpMaxBucket = 192;   // a bucket this full means heavy duplication: not a sparse tile
 constexpr uint32_t kSpBudget = 700;      // candidate tests + extension steps one thread may spend (4 positions)
-constexpr uint32_t kSpSeg = 9;           // window pixels per thread in the run-length pass (256 * 9 >= window)
-static_assert(kSpSources == kWindow + kSpTile, "entry layout");
-static_assert(256 * kSpSeg >= kSpSources + kMaxLen, "run-length pass covers the window");
+constexpr uint32_t kSpSeg = 7;           // window pixels per thread in the run-length pass
+static_assert(kSpSources <= (1u << kSpPosBits) && kSpSources % kSpThreads == 0 && kSpTile % kSpThreads == 0, "entry layout");
+static_assert(kSpThreads * kSpSeg >= kSpSources + kMaxLen, "run-length pass covers the window");
+static_assert(kSpBuckets == 8 * kSpThreads, "8 buckets per thread in the scan");
+static_assert(kSpTile == kLzTile, "one flag per tile");
 
-__global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+__global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                      const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
                                                      const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                                      uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
-  __shared__ __attribute__((aligned(16))) uint32_t px[256 * kSpSeg + 4];
+  __shared__ __attribute__((aligned(16))) uint32_t px[kSpSources + kMaxLen + 4];
   __shared__ uint16_t runlen[kSpSources + kMaxLen];  // pixels equal to this one from here on (within the window)
   __shared__ uint32_t cursor[kSpBuckets];  // counts, then insert positions; after the scatter cursor[h] = end of bucket h
   __shared__ uint32_t items[kSpSources];   // (low bits of the mixed pixel) << 11 | index in px
-  __shared__ uint32_t wsum[4];
-  __shared__ uint32_t wmin[4];
+  __shared__ uint32_t wsum[kSpWaves];
+  __shared__ uint32_t wmin[kSpWaves];
   __shared__ uint32_t s_abort, s_inside;
   constexpr uint32_t kPerSuper = kSuper / kSpTile;
   // Workgroups go round-robin to the 8 XCDs, each with its own L2.  Neighbouring tiles share half of their
@@ -388,19 +392,19 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
   const uint64_t pos0 = imgs[img].pos0;
   const uint32_t *data = pix + pos0;
   const uint32_t lane = tid & 63, wave = tid >> 6;
-  for (uint32_t i = tid; i < kSpBuckets; i += 256) cursor[i] = 0;
+  for (uint32_t i = tid; i < kSpBuckets; i += kSpThreads) cursor[i] = 0;
   if (tid == 0) { s_abort = 0; s_inside = 0; }
   // lo is a multiple of 4 (a and kWindow are) and the pixel array has readable slack past M: 16-byte loads
-  for (uint32_t i = tid * 4; i < W; i += 1024) *reinterpret_cast<uint4 *>(&px[i]) = *reinterpret_cast<const uint4 *>(data + lo + i);
+  for (uint32_t i = tid * 4; i < W; i += kSpThreads * 4) *reinterpret_cast<uint4 *>(&px[i]) = *reinterpret_cast<const uint4 *>(data + lo + i);
   __syncthreads();
   const uint32_t nsrc = b - lo;  // pixels lo..b-1 can be sources
-  uint32_t mixed[kSpSources / 256];  // this thread's sources tid, tid+256, ...: pixel * kSpMul
-  uint32_t first_of_run = 0;         // bit k: source k*256+tid starts a run (or the window)
-  uint32_t valid = 0;                // bit k: source k*256+tid exists
+  uint32_t mixed[kSpSources / kSpThreads];  // this thread's sources tid, tid+512, ...: pixel * kSpMul
+  uint32_t first_of_run = 0;         // bit k: source k*512+tid starts a run (or the window)
+  uint32_t valid = 0;                // bit k: source k*512+tid exists
 #pragma unroll
-  for (uint32_t k = 0; k < kSpSources / 256; k++) {
-    const uint32_t i = k * 256 + tid;
-    mixed[k] = px[i] * kSpMul;  // in bounds: px has kSpSources + kMaxLen entries
+  for (uint32_t k = 0; k < kSpSources / kSpThreads; k++) {
+    const uint32_t i = k * kSpThreads + tid;
+    mixed[k] = px[i] * kSpMul;  // in bounds: px has more than kSpSources entries
     if (i < nsrc) {
       valid |= 1u << k;
       if (i == 0 || px[i - 1] != px[i]) first_of_run |= 1u << k;
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
     const uint32_t s0 = tid * kSpSeg;
     uint32_t v[kSpSeg + 1];
 #pragma unroll
-    for (uint32_t j = 0; j <= kSpSeg; j++) v[j] = px[s0 + j];  // px is padded to 256 * kSpSeg + 1 entries
+    for (uint32_t j = 0; j <= kSpSeg; j++) v[j] = s0 + j < W ? px[s0 + j] : 0u;
     uint32_t ends = 0;  // bit j: a run ends at s0 + j
 #pragma unroll
     for (uint32_t j = 0; j < kSpSeg; j++)
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
     uint32_t after = (uint32_t)__shfl_down((int)m, 1, 64);
     if (lane == 63) after = 0xffffu;
     __syncthreads();
-    for (uint32_t w = wave + 1; w < 4; w++) after = wmin[w] < after ? wmin[w] : after;
+    for (uint32_t w = wave + 1; w < kSpWaves; w++) after = wmin[w] < after ? wmin[w] : after;
     uint32_t end = after;
 #pragma unroll
     for (int j = (int)kSpSeg - 1; j >= 0; j--) {
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
     }
   }
 #pragma unroll
-  for (uint32_t k = 0; k < kSpSources / 256; k++)
+  for (uint32_t k = 0; k < kSpSources / kSpThreads; k++)
     if ((first_of_run >> k) & 1u) atomicAdd(&cursor[mixed[k] >> (32 - kSpPosBits)], 1u);
   __syncthreads();
   // exclusive scan of the bucket counts (8 per thread)
@@ -464,20 +468,20 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
   for (int k = 0; k < 8; k++) { cursor[tid * 8 + k] = run; run += c[k]; }
   __syncthreads();
 #pragma unroll
-  for (uint32_t k = 0; k < kSpSources / 256; k++) {
-    const uint32_t i = k * 256 + tid;
+  for (uint32_t k = 0; k < kSpSources / kSpThreads; k++) {
+    const uint32_t i = k * kSpThreads + tid;
     if ((first_of_run >> k) & 1u) items[atomicAdd(&cursor[mixed[k] >> (32 - kSpPosBits)], 1u)] = (mixed[k] << kSpTagShift) | i;
   }
   __syncthreads();
-  // every thread: positions a+tid, a+tid+256, ...
-  uint32_t out[kSpTile / 256];
+  // every thread: positions a+tid, a+tid+512, ...
+  uint32_t out[kSpTile / kSpThreads];
   uint32_t spent = 0;
   bool over = false;
   auto search = [&](auto plain_c) {
   constexpr bool kPlain = decltype(plain_c)::value;
 #pragma unroll 1
-  for (uint32_t k = 0; k < kSpTile / 256; k++) {
-    const uint32_t p = a + k * 256 + tid;
+  for (uint32_t k = 0; k < kSpTile / kSpThreads; k++) {
+    const uint32_t p = a + k * kSpThreads + tid;
     uint32_t key = 0;  // best so far: length << 11 | distance
     if (p < b && !over) {
       const uint32_t ip = p - lo, x = px[ip];
@@ -520,9 +524,9 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
       if (!kPlain && wlo > 0 && px[wlo] == x && px[wlo - 1] == x) source_run(wlo);  // the run that the window start cuts
       for (uint32_t i = beg; i < end; i++) {
         const uint32_t it = items[i];
-        const uint32_t s = it & (kSpSources - 1);
+        const uint32_t s = it & ((1u << kSpPosBits) - 1);
         spent++;
-        if ((it ^ tag) >= kSpSources || s >= ip || s < wlo) continue;  // another value, or not one of the 1024 before p
+        if ((it ^ tag) >> kSpPosBits || s >= ip || s < wlo) continue;  // another value, or not one of the 1024 before p
         source_run(s);
       }
       if (spent > kSpBudget) over = true;
@@ -536,8 +540,8 @@ __global__ __launch_bounds__(256) void k_lz77_sparse(const EncImage *__restrict_
   __syncthreads();
   if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
 #pragma unroll
-  for (uint32_t k = 0; k < kSpTile / 256; k++) {
-    const uint32_t p = a + k * 256 + tid;
+  for (uint32_t k = 0; k < kSpTile / kSpThreads; k++) {
+    const uint32_t p = a + k * kSpThreads + tid;
     if (p < b) {
       match[pos0 + p] = out[k];
       adv[pos0 + p] = (uint8_t)((out[k] & 0xff) ? (out[k] & 0xff) : 1u);
@@ -1359,7 +1363,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix);
   (void)hipEventRecord(e->ev[2], s);
   if (e->match_mode == 0)
-    hipLaunchKernelGGL(k_lz77_sparse, dim3((gsb * (kSuper / kSpTile) + 7) / 8 * 8), dim3(256), 0, s, imgs, st, sbf, nl,
+    hipLaunchKernelGGL(k_lz77_sparse, dim3((gsb * (kSuper / kSpTile) + 7) / 8 * 8), dim3(kSpThreads), 0, s, imgs, st, sbf, nl,
                        gsb * (kSuper / kSpTile), pix, match, adv8, dense);
   (void)hipEventRecord(e->ev[9], s);  // also when the candidate-list kernel is switched off
   hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, adv8,
