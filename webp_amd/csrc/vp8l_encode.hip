@@ -554,6 +554,8 @@ __global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs,
                                               const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                               uint8_t *__restrict__ adv, const uint8_t *__restrict__ dense_tile) {
   constexpr uint32_t kPerSuper = kSuper / kLzBlock;
+  // tiles the candidate-list kernel completed are done; it flags the ones it gave up on (tile number = wave number)
+  if (dense_tile && __builtin_amdgcn_readfirstlane((int)dense_tile[blockIdx.x * kLzWaves + (threadIdx.x >> 6)]) == 0) return;
   const uint32_t blk = blockIdx.x, sb = blk / kPerSuper, img = find_image(sb_first, n, sb);
   const uint32_t M = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[img].M);
   const int lane = threadIdx.x & 63;
@@ -562,8 +564,6 @@ __global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs,
   if (a >= M) return;
   const uint32_t b = a + kLzTile < M ? a + kLzTile : M;
   const uint64_t pos0 = imgs[img].pos0;
-  // tiles the candidate-list kernel completed are done; it flags the ones it gave up on
-  if (dense_tile && __builtin_amdgcn_readfirstlane((int)dense_tile[(pos0 + a) / kLzTile]) == 0) return;
   const uint32_t xsize = st[img].xsize, xinv = st[img].xinv;
   if (a == 0) lz77_tile<true>(pix + pos0, match + pos0, adv + pos0, M, a, b, lane, xsize, xinv);
   else lz77_tile<false>(pix + pos0, match + pos0, adv + pos0, M, a, b, lane, xsize, xinv);
