@@ -1040,25 +1040,28 @@ struct RunPut {
   __device__ __forceinline__ void finish() { if (fill) atomicOr(&stage[w], (uint32_t)acc); }
 };
 
-// `tab` has (0, 0) for the codes that are not written.  A token of at most 32 bits (nearly all) goes out in one piece.
+// `tab` has (0, 0) for the codes that are not written and one more (0, 0) entry at kTabZero.  Literals and back
+// references differ only in where their four parts come from, so a wave with both kinds runs the lookups, the
+// assembly and the write once.  A token of at most 32 bits (nearly all) goes out in one piece.
+constexpr uint32_t kTabZero = kNumCodes * kCodeStride;
 template <class Put>
 __device__ __forceinline__ void emit_token_packed(Put &put, const uint2 *tab, uint32_t pixel, uint32_t m) {
   const uint32_t len = m & 0xff;
-  uint2 e0, e1, e2, e3;  // (bits, count) of the four parts
-  if (len == 0) {
-    e0 = tab[kGreen * kCodeStride + ((pixel >> 8) & 0xff)];
-    e1 = tab[kRed * kCodeStride + ((pixel >> 16) & 0xff)];
-    e2 = tab[kBlue * kCodeStride + (pixel & 0xff)];
-    e3 = tab[kAlpha * kCodeStride + (pixel >> 24)];
-  } else {
+  uint32_t i0 = kGreen * kCodeStride + ((pixel >> 8) & 0xff), i1 = kRed * kCodeStride + ((pixel >> 16) & 0xff);
+  uint32_t i2 = kBlue * kCodeStride + (pixel & 0xff), i3 = kAlpha * kCodeStride + (pixel >> 24);
+  uint2 x1 = make_uint2(0, 0), x3 = make_uint2(0, 0);  // extra bits of a back reference
+  if (len) {
     uint32_t sym, nb, eb;
     prefix_encode(len, sym, nb, eb);
-    e0 = tab[kGreen * kCodeStride + 256 + sym];
-    e1 = make_uint2(eb, nb);
+    i0 = kGreen * kCodeStride + 256 + sym;
+    x1 = make_uint2(eb, nb);
     prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);
-    e2 = tab[kDist * kCodeStride + sym];
-    e3 = make_uint2(eb, nb);
+    i2 = kDist * kCodeStride + sym;
+    x3 = make_uint2(eb, nb);
+    i1 = i3 = kTabZero;
   }
+  const uint2 e0 = tab[i0], t1 = tab[i1], e2 = tab[i2], t3 = tab[i3];
+  const uint2 e1 = make_uint2(t1.x | x1.x, t1.y | x1.y), e3 = make_uint2(t3.x | x3.x, t3.y | x3.y);
   const uint32_t n1 = e0.y + e1.y, n2 = n1 + e2.y, n = n2 + e3.y;
   if (n <= 32) {
     // a part with no bits has value 0, so a shift count of 32 (taken mod 32) cannot leak anything
@@ -1068,22 +1071,23 @@ __device__ __forceinline__ void emit_token_packed(Put &put, const uint2 *tab, ui
   }
 }
 
-// The tokens of 16 consecutive positions, fetched four at a time.
+// The tokens of 16 consecutive positions; all eight 16-byte loads are issued before the first token is written.
 template <class Put>
 __device__ __forceinline__ void emit_group(Put &put, const uint2 *tab, const uint32_t *__restrict__ px,
                                            const uint32_t *__restrict__ mt, uint32_t fl) {
-  uint4 m4 = *reinterpret_cast<const uint4 *>(mt), p4 = *reinterpret_cast<const uint4 *>(px);
-#pragma unroll 1
+  uint4 m4[4], p4[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    m4[g] = reinterpret_cast<const uint4 *>(mt)[g];
+    p4[g] = reinterpret_cast<const uint4 *>(px)[g];
+  }
+#pragma unroll
   for (int g = 0; g < 4; g++, fl >>= 4) {
-    const uint4 mc = m4, pc = p4;
-    if (g < 3) {  // the next four while these are written
-      m4 = *reinterpret_cast<const uint4 *>(mt + 4 * g + 4);
-      p4 = *reinterpret_cast<const uint4 *>(px + 4 * g + 4);
-    }
-    if (fl & 1u) emit_token_packed(put, tab, pc.x, mc.x);
-    if (fl & 2u) emit_token_packed(put, tab, pc.y, mc.y);
-    if (fl & 4u) emit_token_packed(put, tab, pc.z, mc.z);
-    if (fl & 8u) emit_token_packed(put, tab, pc.w, mc.w);
+    if ((fl & 15u) == 0) continue;
+    if (fl & 1u) emit_token_packed(put, tab, p4[g].x, m4[g].x);
+    if (fl & 2u) emit_token_packed(put, tab, p4[g].y, m4[g].y);
+    if (fl & 4u) emit_token_packed(put, tab, p4[g].z, m4[g].z);
+    if (fl & 8u) emit_token_packed(put, tab, p4[g].w, m4[g].w);
   }
   put.finish();
 }
@@ -1094,19 +1098,20 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
                                               const uint32_t *__restrict__ flags, const CodeTables *__restrict__ tables,
                                               const uint16_t *__restrict__ group_bits, const uint64_t *__restrict__ unit_off,
                                               uint8_t *__restrict__ out) {
-  __shared__ uint2 tab[kNumCodes * kCodeStride];  // (code, length)
+  __shared__ uint2 tab[kNumCodes * kCodeStride + 1];  // (code, length), and a zero entry
   __shared__ uint32_t stage[kWinWords + 2];
   __shared__ uint32_t wsum[4];
-  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  // one superblock (four units) per workgroup: the code tables are fetched into LDS once for 16384 positions
+  const uint32_t sb = blockIdx.x, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   if (st[img].status != 0) return;
   const uint32_t M = st[img].M;
-  const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
-  if (p0 >= M) return;
+  if ((sb - sb_first[img]) * kSuper >= M) return;
   const CodeTables *T = &tables[img];
   for (uint32_t i = tid; i < kNumCodes * kCodeStride / 4; i += 256) {  // four (code, length) entries at a time
     const uint4 c4 = reinterpret_cast<const uint4 *>(T->code)[i];
     const uint32_t l4 = reinterpret_cast<const uint32_t *>(T->len)[i];
+    if (i == 0) tab[kTabZero] = make_uint2(0, 0);
     const bool off = code_unwritten(T, 4 * i);  // kCodeStride is a multiple of 4: the four entries belong to one code part
     tab[4 * i + 0] = off ? make_uint2(0, 0) : make_uint2(c4.x, l4 & 0xff);
     tab[4 * i + 1] = off ? make_uint2(0, 0) : make_uint2(c4.y, (l4 >> 8) & 0xff);
@@ -1115,6 +1120,11 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
   }
   const EncImage im = imgs[img];
   const uint64_t pos0 = im.pos0;
+  uint32_t *out32 = reinterpret_cast<uint32_t *>(out + im.out_off);
+  for (uint32_t u = 0; u < kUnitsPerSuper; u++) {
+  const uint32_t unit = sb * kUnitsPerSuper + u;
+  const uint32_t p0 = (sb - sb_first[img]) * kSuper + u * kUnit;
+  if (p0 >= M) break;
   // this thread's 16 consecutive positions (the arrays have readable slack past M)
   const uint32_t pb = p0 + tid * 16;
   const uint32_t *mt = match + pos0 + pb, *px = pix + pos0 + pb;
@@ -1126,16 +1136,16 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
   }
   const uint32_t incl = wave_incl_scan_u32(mybits, (int)lane);
   if (lane == 63) wsum[wave] = incl;
-  __syncthreads();
+  __syncthreads();  // also: the tables are in LDS, the previous unit's words are out
   uint32_t before = 0;
   for (uint32_t k = 0; k < wave; k++) before += wsum[k];
   const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  if (total == 0) return;
+  __syncthreads();  // wsum is read before the next unit overwrites it
+  if (total == 0) continue;
   const uint64_t start_bit = unit_off[unit], end_bit = start_bit + total;
   const uint64_t my_bit = start_bit + before + incl - mybits;
   const uint64_t first_word = start_bit >> 5, last_word = (end_bit - 1) >> 5;
   const uint64_t nwords = last_word - first_word + 1;
-  uint32_t *out32 = reinterpret_cast<uint32_t *>(out + im.out_off);
   constexpr long long kWinBits = (long long)kWinWords * 32;
   for (uint64_t wbase = 0; wbase < nwords; wbase += kWinWords) {
     const uint64_t cntw = nwords - wbase < kWinWords ? nwords - wbase : kWinWords;
@@ -1159,6 +1169,7 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
       if (shared) atomicOr(&out32[gw], stage[i]); else out32[gw] = stage[i];
     }
     __syncthreads();
+  }
   }
 }
 
@@ -1380,7 +1391,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, gbits, ubits);
   hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, imgs, st, sbf, ubits, uoff, d_out);
   (void)hipEventRecord(e->ev[7], s);
-  hipLaunchKernelGGL(k_emit, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, gbits, uoff, d_out);
+  hipLaunchKernelGGL(k_emit, dim3(gsb), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, gbits, uoff, d_out);
   (void)hipEventRecord(e->ev[8], s);
   if (!hip_ok(hipGetLastError(), "kernel launch")) return VP8L_ERR_HIP;
   if (!hip_ok(hipMemcpyAsync(e->states.data(), st, nl * sizeof(EncState), hipMemcpyDeviceToHost, s), "download state")) return VP8L_ERR_HIP;
