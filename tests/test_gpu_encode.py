@@ -175,3 +175,24 @@ def test_unit_longer_than_the_staging_window():
     assert 8 * (len(got) - len(plain)) > 6144 * 36   # the stretch costs well over 32 bits a pixel
     dec, dw, dh = webp_amd.decode(got)
     assert (dw, dh) == (w, h) and np.array_equal(dec, img)
+
+
+def test_pixels_not_16_byte_aligned():
+    # the match kernel reads the caller's pixels 16 bytes at a time when it can; a pointer that is only
+    # 4-byte aligned takes the separate transform kernel.  Same bytes either way.
+    torch = torch_cuda()
+    w, h = 333, 41
+    img = O.gen_image(3, w, h, 77, 200)
+    rc, ref = O.encode(img, w, h)
+    assert rc == 0
+    enc = webp_amd.Encoder()
+    cap = enc.bound(w, h)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    for shift in (0, 1, 2, 3):
+        buf = torch.zeros(w * h + 8, dtype=torch.int32, device="cuda")
+        buf[shift: shift + w * h] = torch.from_numpy(img.view(np.int32)).cuda()
+        off, lens, status = enc.encode_device([buf.data_ptr() + 4 * shift], [w], [h], d_out.data_ptr(), cap)
+        assert status[0] == 0
+        assert bytes(d_out[int(off[0]): int(off[0]) + int(lens[0])].cpu().numpy()) == ref, shift
+        assert np.array_equal(enc.fetch_stage(0, webp_amd.STAGE_RESIDUAL), O.encode(img, w, h, trace=True)[2]["residual"])
+    enc.close()

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_palette_scan(const EncImage *__restrict
 }
 
 __global__ __launch_bounds__(256) void k_palette_finalize(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
-                                                          const unsigned long long *__restrict__ gsets) {
+                                                          const unsigned long long *__restrict__ gsets, uint32_t fuse) {
   __shared__ uint32_t list[kSetSlots];
   __shared__ uint32_t s_k;
   const uint32_t img = blockIdx.x, tid = threadIdx.x;
@@ -108,7 +108,11 @@ __global__ __launch_bounds__(256) void k_palette_finalize(const EncImage *__rest
   __syncthreads();
   const bool none = s.pal_overflow || s.pal_count > kMaxPalette || s.pal_count == 0;
   if (none) {
-    if (tid == 0) { s.ncolors = 0; s.bits = 0; s.xsize = im.w; s.M = im.w * im.h; s.xinv = dist_inverse(im.w); }
+    if (tid == 0) {
+      s.ncolors = 0; s.bits = 0; s.xsize = im.w; s.M = im.w * im.h; s.xinv = dist_inverse(im.w);
+      // the candidate-list kernel reads 16 bytes at a time straight from the caller's pixels
+      s.fused = fuse && (reinterpret_cast<uintptr_t>(im.argb) & 15) == 0;
+    }
     return;
   }
   const unsigned long long *gset = gsets + (size_t)img * kSetSlots;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void k_transform(const EncImage *__restrict__ 
   const EncImage im = imgs[img];
   const uint32_t M = st[img].M, ncolors = st[img].ncolors;
   const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
-  if (p0 >= M) return;
+  if (p0 >= M || st[img].fused) return;
   uint32_t *dst = pix + im.pos0;
   if (ncolors == 0) {
 #pragma unroll 4
@@ -366,7 +370,7 @@ static_assert(kSpTile == kLzTile, "one flag per tile");
 
 __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                      const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
-                                                     const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
+                                                     uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                                      uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
   __shared__ __attribute__((aligned(16))) uint32_t px[kSpSources + kMaxLen + 4];
   __shared__ uint16_t runlen[kSpSources + kMaxLen];  // pixels equal to this one from here on (within the window)
@@ -395,7 +399,27 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   for (uint32_t i = tid; i < kSpBuckets; i += kSpThreads) cursor[i] = 0;
   if (tid == 0) { s_abort = 0; s_inside = 0; }
   // lo is a multiple of 4 (a and kWindow are) and the pixel array has readable slack past M: 16-byte loads
-  for (uint32_t i = tid * 4; i < W; i += kSpThreads * 4) *reinterpret_cast<uint4 *>(&px[i]) = *reinterpret_cast<const uint4 *>(data + lo + i);
+  if (st[img].fused) {
+    // Subtract-green path: the residual is made here from the caller's pixels (vp8l.h:594-597,
+    // transform.cpp:88-106) and this tile's part of it is stored for the later stages; k_transform skips the image.
+    const uint32_t *argb = imgs[img].argb;  // 16-byte aligned, exactly M pixels
+    for (uint32_t i = tid * 4; i < W; i += kSpThreads * 4) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (lo + i + 4 <= M) {
+        v = *reinterpret_cast<const uint4 *>(argb + lo + i);
+      } else {
+        v.x = argb[lo + i];
+        if (lo + i + 1 < M) v.y = argb[lo + i + 1];
+        if (lo + i + 2 < M) v.z = argb[lo + i + 2];
+      }
+      v.x = subtract_green(v.x); v.y = subtract_green(v.y); v.z = subtract_green(v.z); v.w = subtract_green(v.w);
+      *reinterpret_cast<uint4 *>(&px[i]) = v;
+      const uint32_t p = lo + i;
+      if (p >= a && p < b) *reinterpret_cast<uint4 *>(pix + pos0 + p) = v;  // the region has slack past M
+    }
+  } else {
+    for (uint32_t i = tid * 4; i < W; i += kSpThreads * 4) *reinterpret_cast<uint4 *>(&px[i]) = *reinterpret_cast<const uint4 *>(data + lo + i);
+  }
   __syncthreads();
   const uint32_t nsrc = b - lo;  // pixels lo..b-1 can be sources
   uint32_t mixed[kSpSources / kSpThreads];  // this thread's sources tid, tid+512, ...: pixel * kSpMul
@@ -1369,7 +1393,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   const uint32_t gsb = (uint32_t)sb_total, gunits = (uint32_t)nunits;
   (void)hipEventRecord(e->ev[0], s);
   hipLaunchKernelGGL(k_palette_scan, dim3(gsb), dim3(256), 0, s, imgs, st, sbf, nl, gsets);
-  hipLaunchKernelGGL(k_palette_finalize, dim3(nl), dim3(256), 0, s, imgs, st, gsets);
+  hipLaunchKernelGGL(k_palette_finalize, dim3(nl), dim3(256), 0, s, imgs, st, gsets, e->match_mode == 0 ? 1u : 0u);
   (void)hipEventRecord(e->ev[1], s);
   hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix);
   (void)hipEventRecord(e->ev[2], s);

@@ -35,6 +35,7 @@ struct EncState {          // device-written
   uint32_t xsize;          // coded width
   uint32_t M;              // coded pixels = xsize*h
   uint32_t xinv;           // ceil(2^32 / xsize): division by xsize as a multiplication (dist_to_code_inv)
+  uint32_t fused;          // the match kernel makes the subtract-green residual itself (k_transform skips the image)
   uint32_t hdr_bits;       // bits in front of the first token
   int32_t status;
   uint64_t total_bits;
