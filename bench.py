@@ -8,8 +8,9 @@ HBM; the streams stay in HBM.  With N GPUs every rank encodes its own batch of t
 are independent: no collective on the data path), so value = pixels of all ranks / slowest rank.
 
 Prints ONE JSON line on rank 0.  Extra objects in that line:
-  roofline      the dominant kernel (k_lz77_sparse, the match search): algorithmic bytes (9 B per coded
-                pixel: 4 read, 4 + 1 written) over its mean launch duration, measured here with HIP
+  roofline      the dominant kernel (k_lz77_sparse, the match search, which also makes the subtract-green
+                residual): algorithmic bytes (13 B per coded pixel: 4 read; residual 4, match 4 and
+                advance 1 written) over its mean launch duration, measured here with HIP
                 events on the encoder's stream; "traffic" is the HBM byte count of one launch from the
                 committed rocprofv3 counter passes (profiles/lz77_traffic.json), null if none fits
   cpu_baseline  the CPU oracle (a port of the reference's single-threaded algorithm, image-parallel
@@ -32,7 +33,7 @@ import webp_amd  # noqa: E402
 from webp_amd import sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
-LZ77_BYTES_PER_PIXEL = 9.0     # 4 B pixel read + 4 B (length, distance, code) + 1 B advance written per coded pixel
+LZ77_BYTES_PER_PIXEL = 13.0    # 4 B pixel read; 4 B residual + 4 B (length, distance, code) + 1 B advance written
 
 
 def cpu_baseline(w, h, plan, threads, budget_images):

@@ -6,7 +6,7 @@ summaries under profiles/:
   lz77_traffic.json              what bench.py reports as roofline.traffic for the same workload
 FETCH_SIZE and WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts a 16-byte-per-lane streaming read at half
 its bytes (128-byte requests tallied as 64), so it is doubled; WRITE_SIZE is exact for this kernel (it equals
-5 bytes x coded pixels to the byte)."""
+9 bytes x coded pixels to the byte: residual 4, match 4, advance 1)."""
 import csv, json, os, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01c"
@@ -32,7 +32,7 @@ pmc = {
     "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
     "fetch_bytes_corrected_x2": 2.0 * fetch * 1024, "write_bytes": write * 1024,
     "hbm_bytes_per_launch": hbm, "launch_ms_under_counters": [fms, wms],
-    "algorithmic_bytes_per_launch": 9.0 * batch * w * h,
+    "algorithmic_bytes_per_launch": 13.0 * batch * w * h,
 }
 json.dump(pmc, open(os.path.join(dst, tag + "_pmc_match_kernel.json"), "w"), indent=1)
 json.dump({"batch": batch, "width": w, "height": h, "kernel": kname, "hbm_bytes_per_launch": hbm,
