@@ -48,6 +48,9 @@ def cpu_baseline(w, h, plan, threads, budget_images):
         assert rc == 0
         return len(data)
 
+    t1 = time.perf_counter()
+    work(0)                                  # one image on one thread: the reference's own (single-threaded) situation
+    one = w * h / 1e6 / (time.perf_counter() - t1)
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=threads) as ex:
         sizes = list(ex.map(work, range(len(imgs))))
@@ -57,6 +60,7 @@ def cpu_baseline(w, h, plan, threads, budget_images):
         "value": mp / dt, "unit": "MP/s", "cores": threads, "kind": "port",
         "sample": "%d of the benchmark's %dx%d images (modes %s), one image per host thread, %.1f s wall"
                   % (len(imgs), w, h, "".join(str(m) for m, _ in sample), dt),
+        "single_thread_value": one,
         "bytes": int(sum(sizes)),
     }
 
