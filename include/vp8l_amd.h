@@ -91,7 +91,12 @@ int vp8l_encoder_encode_device(vp8l_encoder *enc, size_t n, const uint32_t *cons
 /* Options.  VP8L_OPT_MATCH_SEARCH: 0 (default) = candidate-list match search with the exhaustive
  * search as fallback for tiles with heavy duplication; 1 = exhaustive search everywhere.  Both give
  * identical streams; the option exists for verification and measurement. */
-enum { VP8L_OPT_MATCH_SEARCH = 1 };
+enum { VP8L_OPT_MATCH_SEARCH = 1, VP8L_OPT_PREDICTOR_BITS = 2 };
+/* VP8L_OPT_PREDICTOR_BITS: 0 (default) = the reference encoder's output (subtract green or colour indexing only,
+ * vp8l.h:594-610).  2..9 = additionally apply the predictor transform (14 modes, one per tile of 2^bits pixels
+ * a side, chosen per tile; the tile size grows until an image has at most 1024 tiles) in front of the same
+ * coder.  The reference DECODER reads such streams (ReadTransform vp8l.h:111-121, transform.h:110-191); they
+ * are much smaller for natural images but of course differ from the reference encoder's bytes. */
 int vp8l_encoder_set_option(vp8l_encoder *enc, int option, int value);
 /* Number of 2048-position tiles of the last call that needed the exhaustive search (and the total). */
 long vp8l_encoder_last_dense_tiles(vp8l_encoder *enc, long *total_tiles);
@@ -103,7 +108,8 @@ enum {
   VP8L_STAGE_MATCH = 1,    /* per position: length | distance<<8 | parse_flag<<31, uint32 x M          */
   VP8L_STAGE_HISTO = 2,    /* 5 x 280 uint32 (GREEN, RED, BLUE, ALPHA, DIST; unused tail zero)           */
   VP8L_STAGE_CODELEN = 3,  /* 5 x 280 uint8 code lengths                                                 */
-  VP8L_STAGE_INFO = 4      /* uint32[4]: ncolors (0 = subtract-green path), bundling bits, xsize, M     */
+  VP8L_STAGE_INFO = 4,     /* uint32[4]: ncolors (0 = subtract-green path), bundling bits, xsize, M     */
+  VP8L_STAGE_PRED_MODES = 5 /* uint32[3] tile bits, columns, rows, then one uint32 per tile (0 bytes: none) */
 };
 long vp8l_encoder_fetch_stage(vp8l_encoder *enc, size_t image, int what, void *host_buf, size_t cap_bytes);
 

@@ -27,7 +27,7 @@ STATUS_NAMES = {
     -5: "InvalidVP8L", -6: "InvalidHuffman", -7: "NoDevice", -8: "MemoryAllocationException", -9: "HipError",
     -10: "BadArgument", -11: "Workspace",
 }
-STAGE_RESIDUAL, STAGE_MATCH, STAGE_HISTO, STAGE_CODELEN, STAGE_INFO = range(5)
+STAGE_RESIDUAL, STAGE_MATCH, STAGE_HISTO, STAGE_CODELEN, STAGE_INFO, STAGE_PRED_MODES = range(6)
 ENCODE_STAGES = ("palette", "transform", "match", "parse", "histogram", "header", "bitcount_scan", "emit",
                  "match_fallback")  # the last one is the part of "match" spent in the exhaustive kernel
 
@@ -240,6 +240,14 @@ class Encoder:
             raise Vp8lError(int(rc), "vp8l_encoder_fetch_stage")
         if what == STAGE_INFO:
             return dict(ncolors=int(info[0]), bits=int(info[1]), xsize=int(info[2]), M=int(info[3]))
+        if what == STAGE_PRED_MODES:
+            buf = np.zeros(3 + 1024, dtype=np.uint32)
+            rc = lib().vp8l_encoder_fetch_stage(self._h, image, what, buf.ctypes.data, buf.nbytes)
+            if rc < 0:
+                raise Vp8lError(int(rc), "vp8l_encoder_fetch_stage")
+            if rc == 0:
+                return None
+            return dict(bits=int(buf[0]), tx=int(buf[1]), ty=int(buf[2]), modes=buf[3:3 + int(buf[1]) * int(buf[2])].copy())
         if what in (STAGE_RESIDUAL, STAGE_MATCH):
             buf = np.zeros(int(info[3]), dtype=np.uint32)
         elif what == STAGE_HISTO:
@@ -257,6 +265,12 @@ class Encoder:
     def set_exhaustive_search(self, on):
         """True: test all 1024 distances everywhere; False (default): candidate lists + fallback."""
         rc = lib().vp8l_encoder_set_option(self._h, 1, 1 if on else 0)
+        if rc != OK:
+            raise Vp8lError(rc, "vp8l_encoder_set_option")
+
+    def set_predictor_bits(self, bits):
+        """0 (default): the reference encoder's output.  2..9: add the predictor transform, tiles of 2**bits."""
+        rc = lib().vp8l_encoder_set_option(self._h, 2, int(bits))
         if rc != OK:
             raise Vp8lError(rc, "vp8l_encoder_set_option")
 

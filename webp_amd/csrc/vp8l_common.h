@@ -31,6 +31,7 @@ constexpr uint32_t kMaxLen = 128;      // LZ77_MAX_LENGTH
 constexpr uint32_t kMaxDim = 16384;    // MAX_ARGB_IMAGE_SIZE
 constexpr uint32_t kMaxCacheBits = 11; // MAX_COLOR_CACHE_BITS
 constexpr uint32_t kMaxPalette = 256;  // PALLETE_MAX_COLORS
+constexpr uint32_t kSmallMax = 1024;   // largest sub-image the header coder takes (a palette, or predictor modes of <= 1024 tiles)
 
 VP8L_HD int alphabet_size(int code) { return code == kGreen ? kAlphabetGreen : code == kDist ? kAlphabetDist : 256; }
 

@@ -233,15 +233,15 @@ VP8L_HD int build_and_write_codes(BitSink &bw, const uint32_t *histo /*[5*kCodeS
   return 0;
 }
 
-// Greedy parse of a SMALL array (the palette, n <= 256) with the reference's rules
+// Greedy parse of a SMALL array (n <= kSmallMax: the palette, or the predictor modes) with the reference's rules
 // (lz77.h:28-93): window 1024, match length <= min(distance, 128, remaining), shortest match 1,
 // farthest candidate wins ties, the final element is always a literal.  adv[p] = match length at
 // p (0 = literal), dst[p] = its distance.  O(n^2): next_mis[d] tracks, while p runs backwards,
 // the first position q >= p with data[q-d] != data[q].
 struct SmallLzScratch {
-  uint16_t next_mis[kMaxPalette + 1];
-  uint16_t len[kMaxPalette];
-  uint16_t dist[kMaxPalette];
+  uint16_t next_mis[kSmallMax + 1];
+  uint16_t len[kSmallMax];
+  uint16_t dist[kSmallMax];
 };
 
 VP8L_HD void small_best_matches(const uint32_t *data, int n, SmallLzScratch &s) {
@@ -267,7 +267,7 @@ struct SubImageScratch {
   SmallLzScratch lz;
   CodeTables tables;
   uint32_t histo[kNumCodes * kCodeStride];
-  uint32_t delta[kMaxPalette];
+  uint32_t delta[kSmallMax];  // the sub-image: palette deltas, or one predictor mode per tile
 };
 
 // Token bits of one position (vp8l.h:545-583).  Emits through `put(value, nbits)`.
@@ -308,21 +308,22 @@ VP8L_HD void histo_token(uint32_t *histo, uint32_t pixel, uint32_t len, uint32_t
 // The pieces of WriteEntropyCodedImage for the palette (vp8l.h:477-510, called from :457 with xsize = n,
 // ysize = 1).  The device computes the matches and the code
 // lengths with many lanes and calls the pieces; write_small_coded_image is the same thing in one go.
-VP8L_HD void small_histogram(const uint32_t *data, int n, SubImageScratch &s) {
+// xsize: the sub-image's width (distance codes depend on it): n for the palette (n x 1), tile columns for predictor modes
+VP8L_HD void small_histogram(const uint32_t *data, int n, uint32_t xsize, SubImageScratch &s) {
   for (int i = 0; i < kNumCodes * kCodeStride; i++) s.histo[i] = 0;
-  for (int p = 0; p < n; p += s.lz.len[p] ? s.lz.len[p] : 1) histo_token(s.histo, data[p], s.lz.len[p], s.lz.dist[p], (uint32_t)n);
+  for (int p = 0; p < n; p += s.lz.len[p] ? s.lz.len[p] : 1) histo_token(s.histo, data[p], s.lz.len[p], s.lz.dist[p], xsize);
 }
-VP8L_HD void small_write_tokens(BitSink &bw, const uint32_t *data, int n, SubImageScratch &s) {
+VP8L_HD void small_write_tokens(BitSink &bw, const uint32_t *data, int n, uint32_t xsize, SubImageScratch &s) {
   for (int p = 0; p < n; p += s.lz.len[p] ? s.lz.len[p] : 1)
-    emit_token([&](uint32_t v, uint32_t nb) { bw.put(v, nb); }, s.tables, data[p], s.lz.len[p], s.lz.dist[p], (uint32_t)n);
+    emit_token([&](uint32_t v, uint32_t nb) { bw.put(v, nb); }, s.tables, data[p], s.lz.len[p], s.lz.dist[p], xsize);
 }
-VP8L_HD int write_small_coded_image(BitSink &bw, const uint32_t *data, int n, SubImageScratch &s) {
+VP8L_HD int write_small_coded_image(BitSink &bw, const uint32_t *data, int n, uint32_t xsize, SubImageScratch &s) {
   bw.put(0, 1);  // no colour cache
   small_best_matches(data, n, s.lz);
-  small_histogram(data, n, s);
+  small_histogram(data, n, xsize, s);
   const int rc = build_and_write_codes(bw, s.histo, s.tables, s.desc);
   if (rc < 0) return rc;
-  small_write_tokens(bw, data, n, s);
+  small_write_tokens(bw, data, n, xsize, s);
   return 0;
 }
 
@@ -346,6 +347,13 @@ VP8L_HD void palette_deltas(const uint32_t *palette, uint32_t ncolors, uint32_t 
   delta[0] = palette[0];
   for (uint32_t i = 1; i < ncolors; i++) delta[i] = px_sub(palette[i], palette[i - 1]);
 }
+// Predictor transform header (ReadTransform vp8l.h:111-121 reads it): present, type 0, tile bits - 2.  Not something the
+// reference encoder writes (vp8l.h:594-610); its decoder reads it.
+VP8L_HD void write_predictor_head(BitSink &bw, uint32_t bits) {
+  bw.put(1, 1);
+  bw.put(0, 2);
+  bw.put(bits - 2, 3);
+}
 VP8L_HD void write_stream_tail(BitSink &bw) {
   bw.put(0, 1);
   bw.put(0, 1);
@@ -356,7 +364,7 @@ VP8L_HD int write_stream_prefix(BitSink &bw, uint32_t w, uint32_t h, const uint3
   write_stream_head(bw, w, h, ncolors);
   if (ncolors) {
     palette_deltas(palette, ncolors, s.delta);
-    const int rc = write_small_coded_image(bw, s.delta, (int)ncolors, s);
+    const int rc = write_small_coded_image(bw, s.delta, (int)ncolors, ncolors, s);
     if (rc < 0) return rc;
   }
   write_stream_tail(bw);

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "vp8l_amd.h"
+#include "vp8l_dec_core.h"  // the predictors (predict, px_*): the forward transform must mirror the inverse
 #include "vp8l_enc_core.h"
 #include "vp8l_host.h"
 #include "vp8l_kernels.h"
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void k_palette_scan(const EncImage *__restrict
 }
 
 __global__ __launch_bounds__(256) void k_palette_finalize(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
-                                                          const unsigned long long *__restrict__ gsets, uint32_t fuse) {
+                                                          const unsigned long long *__restrict__ gsets, uint32_t fuse, uint32_t pred_bits) {
   __shared__ uint32_t list[kSetSlots];
   __shared__ uint32_t s_k;
   const uint32_t img = blockIdx.x, tid = threadIdx.x;
@@ -112,6 +113,13 @@ __global__ __launch_bounds__(256) void k_palette_finalize(const EncImage *__rest
       s.ncolors = 0; s.bits = 0; s.xsize = im.w; s.M = im.w * im.h; s.xinv = dist_inverse(im.w);
       // the candidate-list kernel reads 16 bytes at a time straight from the caller's pixels
       s.fused = fuse && (reinterpret_cast<uintptr_t>(im.argb) & 15) == 0;
+      if (pred_bits) {  // the smallest tile size >= the requested one whose mode image fits the header coder
+        uint32_t b = pred_bits;
+        while (b < 9 && ((im.w + (1u << b) - 1) >> b) * ((im.h + (1u << b) - 1) >> b) > kSmallMax) b++;
+        s.pred_bits = b;
+        s.pred_tx = (im.w + (1u << b) - 1) >> b;
+        s.pred_ty = (im.h + (1u << b) - 1) >> b;
+      }
     }
     return;
   }
@@ -323,6 +331,97 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
     for (int k = 0; k < 15; k++) win[k] = win[k + 16];
 #pragma unroll
     for (int j = 0; j < 16; j++) mis[j] += 16;
+  }
+}
+
+// =============================================================================================
+// Forward predictor transform (optional; the reference encoder has none, its decoder reads it:
+// ReadTransform vp8l.h:111-121, inverse transform.h:110-191).  Works on the subtract-green image.
+// The residual of a pixel needs only ORIGINAL neighbours, so it is one thread per pixel; the mode of
+// a tile is the one with the smallest sum of absolute residuals (bytes taken as signed), estimated
+// on every second row and column of the tile.  Border rules as in the inverse: (0,0) predicts
+// 0xff000000, the first row predicts L, the first column T, and TR of the last column is L.
+// =============================================================================================
+__device__ __forceinline__ uint32_t abs_cost(uint32_t r) {  // sum over the four bytes of min(b, 256 - b)
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t b = (r >> (8 * k)) & 0xff;
+    c += b < 128 ? b : 256 - b;
+  }
+  return c;
+}
+
+__global__ __launch_bounds__(256) void k_pred_modes(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                    const uint32_t *__restrict__ pix, uint32_t *__restrict__ modes) {
+  __shared__ uint32_t wcost[4][14];
+  const uint32_t img = blockIdx.x / kSmallMax, tile = blockIdx.x % kSmallMax, tid = threadIdx.x;
+  const EncState &s = st[img];
+  const uint32_t bits = s.pred_bits;
+  if (bits == 0 || s.ncolors || tile >= s.pred_tx * s.pred_ty) return;
+  const uint32_t w = imgs[img].w, h = imgs[img].h;
+  const uint32_t *src = pix + imgs[img].pos0;
+  const uint32_t tx = tile % s.pred_tx, ty = tile / s.pred_tx, side = 1u << bits;
+  const uint32_t x0 = tx << bits, y0 = ty << bits;
+  uint32_t cost[14];
+#pragma unroll
+  for (int m = 0; m < 14; m++) cost[m] = 0;
+  const uint32_t half = side >> 1;  // samples per tile side
+  for (uint32_t k = tid; k < half * half; k += 256) {
+    const uint32_t x = x0 + 2 * (k % half) + 1, y = y0 + 2 * (k / half) + 1;  // odd offsets: never the first row or column
+    if (x >= w || y >= h) continue;
+    const uint64_t i = (uint64_t)y * w + x;
+    const uint32_t cur = src[i], L = src[i - 1], T = src[i - w], TL = src[i - w - 1];
+    const uint32_t TR = x == w - 1 ? L : src[i - w + 1];
+#pragma unroll
+    for (int m = 0; m < 14; m++) cost[m] += abs_cost(px_sub(cur, predict((uint32_t)m, L, T, TR, TL)));
+  }
+#pragma unroll
+  for (int m = 0; m < 14; m++) {
+    const uint32_t v = wave_sum_u32(cost[m]);
+    if ((tid & 63) == 0) wcost[tid >> 6][m] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t best = 0, bestc = 0xffffffffu;
+    for (uint32_t m = 0; m < 14; m++) {
+      const uint32_t c = wcost[0][m] + wcost[1][m] + wcost[2][m] + wcost[3][m];
+      if (c < bestc) { bestc = c; best = m; }
+    }
+    modes[(size_t)img * kSmallMax + tile] = 0xff000000u | (best << 8);  // the mode sits in the green byte (transform.h:181)
+  }
+}
+
+// dst = residual (predictor images) or a copy (all others), so that later stages read one array
+__global__ __launch_bounds__(256) void k_pred_residual(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                       const uint32_t *__restrict__ sb_first, uint32_t n,
+                                                       const uint32_t *__restrict__ pix, const uint32_t *__restrict__ modes,
+                                                       uint32_t *__restrict__ dst) {
+  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  const EncState &s = st[img];
+  const uint32_t M = s.M;
+  const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
+  if (p0 >= M) return;
+  const uint64_t pos0 = imgs[img].pos0;
+  const uint32_t *src = pix + pos0;
+  uint32_t *out = dst + pos0;
+  const uint32_t bits = s.ncolors ? 0u : s.pred_bits, w = imgs[img].w;
+  const uint32_t *mimg = modes + (size_t)img * kSmallMax;
+  for (uint32_t k = 0; k < kUnit / 256; k++) {
+    const uint32_t p = p0 + k * 256 + tid;
+    if (p >= M) break;
+    const uint32_t cur = src[p];
+    if (bits == 0) { out[p] = cur; continue; }
+    const uint32_t y = p / w, x = p - y * w;
+    uint32_t P;
+    if (y == 0) P = x == 0 ? 0xff000000u : src[p - 1];
+    else if (x == 0) P = src[p - w];
+    else {
+      const uint32_t L = src[p - 1];
+      const uint32_t mode = (mimg[(y >> bits) * s.pred_tx + (x >> bits)] >> 8) & 0xff;
+      P = predict(mode, L, src[p - w], x == w - 1 ? L : src[p - w + 1], src[p - w - 1]);
+    }
+    out[p] = px_sub(cur, P);
   }
 }
 
@@ -834,7 +933,7 @@ __device__ __forceinline__ void build_codes_4waves(const uint32_t *histo5, CodeT
 // (palette matches, sorting) use the workgroup; the bits are written by one lane, in stream order.
 __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
                                                         const uint32_t *__restrict__ histo, CodeTables *__restrict__ tables,
-                                                        uint8_t *__restrict__ out) {
+                                                        const uint32_t *__restrict__ modes, uint8_t *__restrict__ out) {
   __shared__ HeaderShared sh;
   __shared__ BitSink bw;
   __shared__ int s_rc;
@@ -851,19 +950,28 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
   }
   __syncthreads();
   HuffScratch &hs = wave == 0 ? sh.sub.desc.huff : sh.huff[wave - 1];
-  if (ncolors) {  // the palette as a coded image of ncolors x 1 (vp8l.h:455-457)
-    const int np = (int)ncolors;
+  // A sub-image goes in front of the main image's codes: the palette as ncolors x 1 (vp8l.h:455-457), or the
+  // predictor modes as pred_tx x pred_ty (read by ReadTransform vp8l.h:111-121).
+  const uint32_t pred_bits = ncolors ? 0u : st[img].pred_bits;
+  const int np = ncolors ? (int)ncolors : pred_bits ? (int)(st[img].pred_tx * st[img].pred_ty) : 0;
+  const uint32_t sub_xsize = ncolors ? ncolors : st[img].pred_tx;
+  if (np) {
     uint32_t *d = sh.sub.delta;
-    if (tid < ncolors) d[tid] = tid ? px_sub(sh.palette[tid], sh.palette[tid - 1]) : sh.palette[0];
+    if (ncolors) {
+      if (tid < ncolors) d[tid] = tid ? px_sub(sh.palette[tid], sh.palette[tid - 1]) : sh.palette[0];
+    } else {
+      for (int i = (int)tid; i < np; i += 256) d[i] = modes[(size_t)img * kSmallMax + i];
+      if (tid == 0) write_predictor_head(bw, pred_bits);
+    }
     __syncthreads();
-    if ((int)tid < np) {  // best match of every position, same rules as small_best_matches
-      const int p = (int)tid;
+    for (int p = (int)tid; p < np; p += 256) {  // best match of every position, same rules as small_best_matches
       const int rem = np - p < (int)kMaxLen ? np - p : (int)kMaxLen;
       int best = 0, bestd = 0;
       const uint32_t x = d[p];
       for (int dd = 1; dd <= p; dd++) {
         if (d[p - dd] != x) continue;
         const int maxl = dd < rem ? dd : rem;
+        if (maxl < best) continue;  // cannot reach the best so far; an equally long, farther one replaces it
         int l = 1;
         while (l < maxl && d[p - dd + l] == d[p + l]) l++;
         if (l >= best) { best = l; bestd = dd; }  // farthest among equals
@@ -873,7 +981,7 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
       sh.sub.lz.dist[p] = (uint16_t)bestd;
     }
     __syncthreads();
-    if (tid == 0) small_histogram(d, np, sh.sub);
+    if (tid == 0) small_histogram(d, np, sub_xsize, sh.sub);
     __syncthreads();
     build_codes_4waves(sh.sub.histo, sh.sub.tables, sh.rc, hs, wave, lane);
     if (tid == 0) {
@@ -881,7 +989,7 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
       int rc = 0;
       for (int c = 0; c < kNumCodes && rc == 0; c++)
         rc = sh.rc[c] < 0 ? sh.rc[c] : write_code_desc(bw, sh.sub.tables.len + c * kCodeStride, alphabet_size(c), sh.sub.desc);
-      if (rc == 0) small_write_tokens(bw, d, np, sh.sub);
+      if (rc == 0) small_write_tokens(bw, d, np, sub_xsize, sh.sub);
       s_rc = rc;
     }
     __syncthreads();
@@ -1261,8 +1369,11 @@ struct vp8l_encoder {
   std::mutex mu;
   // workspace (grown on demand)
   DeviceBuffer d_imgs, d_state, d_sbfirst, d_gsets, d_pix, d_match, d_flags, d_histo, d_tables, d_sx, d_entry,
-      d_unit_bits, d_unit_off, d_dense, d_group_bits, d_adv;
+      d_unit_bits, d_unit_off, d_dense, d_group_bits, d_adv, d_pix2, d_modes;
   int match_mode = 0;  // 0 = candidate lists with exhaustive fallback, 1 = exhaustive only
+  const uint32_t *last_pix = nullptr;  // coded pixels of the last call (for fetch_stage)
+  bool last_pred = false;
+  int pred_bits = 0;   // 0 = no predictor transform (the reference encoder's output), else requested tile bits 2..9
   // last batch
   std::vector<EncImage> imgs;
   std::vector<EncState> states;
@@ -1299,7 +1410,7 @@ extern "C" void vp8l_encoder_destroy(vp8l_encoder *e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   DeviceBuffer *bufs[] = {&e->d_imgs, &e->d_state, &e->d_sbfirst, &e->d_gsets, &e->d_pix, &e->d_match, &e->d_flags,
-                          &e->d_histo, &e->d_tables, &e->d_sx, &e->d_entry, &e->d_unit_bits, &e->d_unit_off, &e->d_dense, &e->d_group_bits, &e->d_adv};
+                          &e->d_histo, &e->d_tables, &e->d_sx, &e->d_entry, &e->d_unit_bits, &e->d_unit_off, &e->d_dense, &e->d_group_bits, &e->d_adv, &e->d_pix2, &e->d_modes};
   for (auto *b : bufs) b->release();
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -1360,7 +1471,8 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
             e->d_histo.reserve((size_t)nl * kNumCodes * kCodeStride * 4) && e->d_tables.reserve((size_t)nl * sizeof(CodeTables)) &&
             e->d_sx.reserve(sb_total * kBlockLen) && e->d_entry.reserve(sb_total) &&
             e->d_unit_bits.reserve(nunits * 4) && e->d_unit_off.reserve(nunits * 8) &&
-            e->d_dense.reserve(sb_total * (kSuper / kLzTile)) && e->d_group_bits.reserve(npos / 16 * 2) && e->d_adv.reserve(npos);
+            e->d_dense.reserve(sb_total * (kSuper / kLzTile)) && e->d_group_bits.reserve(npos / 16 * 2) && e->d_adv.reserve(npos) &&
+            (e->pred_bits == 0 || (e->d_pix2.reserve(npos * 4) && e->d_modes.reserve((size_t)nl * kSmallMax * 4)));
   if (!ok) return VP8L_ERR_NO_MEMORY;
 
   hipStream_t s = e->stream;
@@ -1368,7 +1480,10 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   auto *st = e->d_state.as<EncState>();
   auto *sbf = e->d_sbfirst.as<uint32_t>();
   auto *gsets = e->d_gsets.as<unsigned long long>();
-  auto *pix = e->d_pix.as<uint32_t>();
+  auto *pix_t = e->d_pix.as<uint32_t>();                          // output of the pixel transform
+  const uint32_t pred = (uint32_t)e->pred_bits;
+  auto *pix = pred ? e->d_pix2.as<uint32_t>() : pix_t;            // what the match search and the coder read
+  auto *modes = pred ? e->d_modes.as<uint32_t>() : nullptr;
   auto *match = e->d_match.as<uint32_t>();
   auto *flags = e->d_flags.as<uint32_t>();
   auto *histo = e->d_histo.as<uint32_t>();
@@ -1393,9 +1508,13 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   const uint32_t gsb = (uint32_t)sb_total, gunits = (uint32_t)nunits;
   (void)hipEventRecord(e->ev[0], s);
   hipLaunchKernelGGL(k_palette_scan, dim3(gsb), dim3(256), 0, s, imgs, st, sbf, nl, gsets);
-  hipLaunchKernelGGL(k_palette_finalize, dim3(nl), dim3(256), 0, s, imgs, st, gsets, e->match_mode == 0 ? 1u : 0u);
+  hipLaunchKernelGGL(k_palette_finalize, dim3(nl), dim3(256), 0, s, imgs, st, gsets, (e->match_mode == 0 && !pred) ? 1u : 0u, pred);
   (void)hipEventRecord(e->ev[1], s);
-  hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix);
+  hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix_t);
+  if (pred) {
+    hipLaunchKernelGGL(k_pred_modes, dim3(nl * kSmallMax), dim3(256), 0, s, imgs, st, pix_t, modes);
+    hipLaunchKernelGGL(k_pred_residual, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix_t, modes, pix);
+  }
   (void)hipEventRecord(e->ev[2], s);
   if (e->match_mode == 0)
     hipLaunchKernelGGL(k_lz77_sparse, dim3((gsb * (kSuper / kSpTile) + 7) / 8 * 8), dim3(kSpThreads), 0, s, imgs, st, sbf, nl,
@@ -1410,7 +1529,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   (void)hipEventRecord(e->ev[4], s);
   hipLaunchKernelGGL(k_histogram, dim3(gsb), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, histo);
   (void)hipEventRecord(e->ev[5], s);
-  hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, imgs, st, histo, tables, d_out);
+  hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, imgs, st, histo, tables, modes, d_out);
   (void)hipEventRecord(e->ev[6], s);
   hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, gbits, ubits);
   hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, imgs, st, sbf, ubits, uoff, d_out);
@@ -1433,6 +1552,8 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   (void)hipEventElapsedTime(&ms, e->ev[9], e->ev[3]);  // the exhaustive kernel alone (part of stage 2)
   e->stage_seconds[8] = ms * 1e-3;
   e->last_out = d_out;
+  e->last_pix = pix;
+  e->last_pred = pred != 0;
   for (uint32_t k = 0; k < nl; k++) {
     const size_t i = live[k];
     status[i] = e->states[k].status;
@@ -1463,7 +1584,15 @@ extern "C" long vp8l_encoder_fetch_stage(vp8l_encoder *e, size_t image, int what
   size_t bytes = 0;
   uint32_t info[4];
   switch (what) {
-    case VP8L_STAGE_RESIDUAL: src = e->d_pix.as<uint32_t>() + im.pos0; bytes = (size_t)st.M * 4; break;
+    case VP8L_STAGE_RESIDUAL: src = e->last_pix + im.pos0; bytes = (size_t)st.M * 4; break;
+    case VP8L_STAGE_PRED_MODES:  // uint32[3] = bits, tile columns, tile rows; then one uint32 per tile (mode << 8 | 0xff000000)
+      if (!e->last_pred || st.ncolors || st.pred_bits == 0) return 0;
+      info[0] = st.pred_bits; info[1] = st.pred_tx; info[2] = st.pred_ty;
+      bytes = 12 + (size_t)st.pred_tx * st.pred_ty * 4;
+      if (bytes > cap) return VP8L_ERR_BAD_ARGUMENT;
+      memcpy(host_buf, info, 12);
+      if (!hip_ok(hipMemcpy(static_cast<uint8_t *>(host_buf) + 12, e->d_modes.as<uint32_t>() + slot * kSmallMax, bytes - 12, hipMemcpyDeviceToHost), "fetch modes")) return VP8L_ERR_HIP;
+      return (long)bytes;
     case VP8L_STAGE_MATCH: src = e->d_match.as<uint32_t>() + im.pos0; bytes = (size_t)st.M * 4; break;
     case VP8L_STAGE_HISTO: src = e->d_histo.as<uint32_t>() + slot * kNumCodes * kCodeStride; bytes = kNumCodes * kCodeStride * 4; break;
     case VP8L_STAGE_CODELEN: src = e->d_tables.as<CodeTables>()[slot].len; bytes = kNumCodes * kCodeStride; break;
@@ -1493,6 +1622,7 @@ extern "C" int vp8l_encoder_set_option(vp8l_encoder *e, int option, int value) {
   if (!e) return VP8L_ERR_BAD_ARGUMENT;
   std::lock_guard<std::mutex> lock(e->mu);
   if (option == VP8L_OPT_MATCH_SEARCH && (value == 0 || value == 1)) { e->match_mode = value; return VP8L_OK; }
+  if (option == VP8L_OPT_PREDICTOR_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->pred_bits = value; return VP8L_OK; }
   return VP8L_ERR_BAD_ARGUMENT;
 }
 
