@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Per-stage device times of the encoder for one kind of synthetic content (development aid).
 
-usage: stage_probe.py MODE [BATCH] [W] [H] [--exhaustive]"""
+usage: stage_probe.py MODE [BATCH] [W] [H] [--exhaustive] [--predictor=BITS]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import webp_amd
 
-mode = int(sys.argv[1]); batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-w = int(sys.argv[3]) if len(sys.argv) > 3 else 3840; h = int(sys.argv[4]) if len(sys.argv) > 4 else 2160
+pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+mode = int(pos[0]); batch = int(pos[1]) if len(pos) > 1 else 64
+w = int(pos[2]) if len(pos) > 2 else 3840; h = int(pos[3]) if len(pos) > 3 else 2160
 webp_amd.init()
 d_in = torch.empty((batch, w * h), dtype=torch.int32, device="cuda")
 for k in range(batch):
@@ -16,6 +17,9 @@ for k in range(batch):
 enc = webp_amd.Encoder()
 if "--exhaustive" in sys.argv:
     enc.set_exhaustive_search(True)
+for a in sys.argv:
+    if a.startswith("--predictor="):
+        enc.set_predictor_bits(int(a.split("=")[1]))
 cap = enc.bound(w, h)
 d_out = torch.empty(batch * cap, dtype=torch.uint8, device="cuda")
 ptrs = [d_in[k].data_ptr() for k in range(batch)]
