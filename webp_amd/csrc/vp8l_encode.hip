@@ -5,8 +5,11 @@
 //   k_palette_scan / k_palette_finalize   CreatePallete            vp8l.h:372-380
 //   k_transform                           subtract green / colour indexing + bundling
 //                                                                  vp8l.h:411-459, transform.cpp:88-106
-//   k_lz77                                LZ77<uint32_t>::pack best match at every position
-//                                                                  lz77.h:51-72
+//   k_pred_modes / k_pred_residual        optional forward predictor (inverse: transform.h:110-191)
+//   k_lz77_sparse                         LZ77<uint32_t>::pack best match at every position, from candidate
+//                                         lists (also makes the subtract-green residual when it can)
+//   k_lz77                                the same by testing all 1024 distances: fallback for tiles the
+//                                         candidate lists give up on                  lz77.h:51-72
 //   k_parse_exits / k_parse_chain / k_parse_mark   the greedy parse (which positions start a token)
 //                                                                  lz77.h:33-92
 //   k_histogram                           the five symbol histograms          vp8l.h:516-535

@@ -55,15 +55,6 @@ __device__ __forceinline__ uint32_t find_image(const uint32_t *__restrict__ sb_f
   return lo;
 }
 
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
-    v = v > t ? v : t;
-  }
-  return v;
-}
-
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
