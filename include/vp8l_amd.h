@@ -48,7 +48,10 @@ const char *vp8l_last_error(void); /* thread-local text of the last HIP failure 
 /* ---- one image, host memory ------------------------------------------------------------
  * vp8l_encode replaces `VP8_LOSSLESS_ENCODER(argb, width, height)` + `get_bit_writer()`
  * (vp8l.h:585-615).  argb: width*height pixels 0xAARRGGBB, borrowed.  *out is allocated by the
- * library (release with vp8l_free) and holds *out_len bytes.  flags must be 0. */
+ * library (release with vp8l_free) and holds *out_len bytes.  flags = 0 gives the reference encoder's bytes;
+ * flags = 2..9 (VP8L_FLAG_PREDICTOR_BITS_MASK) adds the predictor transform with that tile size, see
+ * VP8L_OPT_PREDICTOR_BITS below. */
+#define VP8L_FLAG_PREDICTOR_BITS_MASK 0xFu
 int vp8l_encode(const uint32_t *argb, uint32_t width, uint32_t height, uint8_t **out, size_t *out_len,
                 uint32_t flags);
 

@@ -100,3 +100,18 @@ def test_full_size_round_trip_and_size():
     assert pm["bits"] == 7 and pm["tx"] * pm["ty"] == 30 * 17      # 5 asked, 7 is the first with <= 1024 tiles
     enc.close()
     print("bytes without / with predictor:", sizes)
+
+
+def test_one_shot_entry_point_with_flags():
+    img = O.gen_image(3, 96, 64, 5, 200)
+    plain = webp_amd.encode(img, 96, 64)
+    rc, ref = O.encode(img, 96, 64)
+    assert rc == 0 and plain == ref
+    small = webp_amd.encode(img, 96, 64, predictor_bits=3)
+    assert small != plain
+    got, w, h = webp_amd.decode(small)
+    assert (w, h) == (96, 64) and np.array_equal(got, img)
+    assert webp_amd.encode(img, 96, 64) == ref           # the plain context is untouched by the flagged call
+    for bad in (1, 10, 16):
+        with pytest.raises(webp_amd.Vp8lError):
+            webp_amd.encode(img, 96, 64, predictor_bits=bad)

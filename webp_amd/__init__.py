@@ -113,12 +113,13 @@ def init():
 
 
 # ------------------------------------------------------------------ host-memory forms
-def encode(argb, width, height):
-    """VP8_LOSSLESS_ENCODER(argb, width, height).get_bit_writer() -> stream bytes (vp8l.h:585-615)."""
+def encode(argb, width, height, predictor_bits=0):
+    """VP8_LOSSLESS_ENCODER(argb, width, height).get_bit_writer() -> stream bytes (vp8l.h:585-615).
+    predictor_bits 2..9 adds the predictor transform (not the reference encoder's bytes any more)."""
     a = None if argb is None else np.ascontiguousarray(argb, dtype=np.uint32)
     out = C.c_void_p()
     n = C.c_size_t()
-    rc = lib().vp8l_encode(a.ctypes.data if a is not None and a.size else None, width, height, C.byref(out), C.byref(n), 0)
+    rc = lib().vp8l_encode(a.ctypes.data if a is not None and a.size else None, width, height, C.byref(out), C.byref(n), int(predictor_bits))
     if rc != OK:
         raise Vp8lError(rc, "vp8l_encode")
     data = C.string_at(out.value, n.value)

@@ -62,18 +62,24 @@ HostContexts &contexts() {
   return *c;
 }
 
-int get_encoder(int device, vp8l_encoder **e) {
+// one shared context per (device, predictor setting): callers with different flags never share option state
+int get_encoder(int device, int pred_bits, vp8l_encoder **e) {
   int dev = device;
   int rc = select_device(device, &dev);
   if (rc != VP8L_OK) return rc;
   HostContexts &c = contexts();
   std::lock_guard<std::mutex> lock(c.mu);
-  auto it = c.enc.find(dev);
+  const int key = dev * 16 + pred_bits;
+  auto it = c.enc.find(key);
   if (it == c.enc.end()) {
     vp8l_encoder *ne = nullptr;
     rc = vp8l_encoder_create(dev, &ne);
     if (rc != VP8L_OK) return rc;
-    it = c.enc.emplace(dev, ne).first;
+    if (pred_bits && vp8l_encoder_set_option(ne, VP8L_OPT_PREDICTOR_BITS, pred_bits) != VP8L_OK) {
+      vp8l_encoder_destroy(ne);
+      return VP8L_ERR_BAD_ARGUMENT;
+    }
+    it = c.enc.emplace(key, ne).first;
   }
   *e = it->second;
   return VP8L_OK;
@@ -155,12 +161,13 @@ extern "C" int vp8l_get_info(const uint8_t *data, size_t len, uint32_t *width, u
   return VP8L_OK;
 }
 
-extern "C" int vp8l_encode_batch(int device, size_t n, const uint32_t *const *argb, const uint32_t *width,
-                                 const uint32_t *height, uint8_t **out, size_t *out_len, int *status) {
+namespace {
+int encode_batch_with(int device, int pred_bits, size_t n, const uint32_t *const *argb, const uint32_t *width,
+                      const uint32_t *height, uint8_t **out, size_t *out_len, int *status) {
   if (!argb || !width || !height || !out || !out_len || !status) return VP8L_ERR_BAD_ARGUMENT;
   if (n == 0) return VP8L_OK;
   vp8l_encoder *e = nullptr;
-  int rc = get_encoder(device, &e);
+  int rc = get_encoder(device, pred_bits, &e);
   if (rc != VP8L_OK) return rc;
   // stage inputs in one device buffer, outputs in another
   std::vector<size_t> in_off(n, 0);
@@ -199,14 +206,21 @@ extern "C" int vp8l_encode_batch(int device, size_t n, const uint32_t *const *ar
   }
   return VP8L_OK;
 }
+}  // namespace
+
+extern "C" int vp8l_encode_batch(int device, size_t n, const uint32_t *const *argb, const uint32_t *width,
+                                 const uint32_t *height, uint8_t **out, size_t *out_len, int *status) {
+  return encode_batch_with(device, 0, n, argb, width, height, out, out_len, status);
+}
 
 extern "C" int vp8l_encode(const uint32_t *argb, uint32_t width, uint32_t height, uint8_t **out, size_t *out_len, uint32_t flags) {
-  if (!out || !out_len || flags != 0) return VP8L_ERR_BAD_ARGUMENT;
+  const int pred_bits = (int)(flags & VP8L_FLAG_PREDICTOR_BITS_MASK);
+  if (!out || !out_len || (flags & ~(uint32_t)VP8L_FLAG_PREDICTOR_BITS_MASK) || pred_bits == 1 || pred_bits > 9) return VP8L_ERR_BAD_ARGUMENT;
   // argument checks of the reference constructor, in its order (vp8l.h:587-590)
   if (!argb || width == 0 || height == 0) return VP8L_ERR_INVALID_ARGB;
   if (width > kMaxDim || height > kMaxDim) return VP8L_ERR_TOO_BIG_ARGB;
   int status = VP8L_OK;
-  const int rc = vp8l_encode_batch(-1, 1, &argb, &width, &height, out, out_len, &status);
+  const int rc = encode_batch_with(-1, pred_bits, 1, &argb, &width, &height, out, out_len, &status);
   return rc != VP8L_OK ? rc : status;
 }
 
