@@ -75,7 +75,7 @@ struct HuffTable {
 constexpr int kSortedPerGroup = kMaxAlphabet + 3 * 256 + kAlphabetDist;
 struct GroupTables {
   HuffTable t[kNumCodes];
-  uint16_t sorted[kSortedPerGroup];
+  uint16_t *sorted;  // kSortedPerGroup entries; only codes longer than the lookup table read it, so it may live in slow memory
 };
 
 VP8L_HD uint32_t dec_bit_reverse(uint32_t v, int len) {
@@ -190,6 +190,14 @@ struct XformRec {
   uint64_t data_off;  // offset of the tile data / palette in the aux buffer (uint32 units)
 };
 
+// What reading one code needs (huffman_io.h:92-195): the code-length code and the lengths being assembled.
+struct DecTableScratch {
+  TableScratch ts;
+  HuffTable cl;
+  uint16_t cl_sorted[kNumClSyms];
+  uint8_t lengths[kMaxAlphabet];
+};
+
 struct DecState {
   // set by the caller
   const uint8_t *data;
@@ -223,11 +231,8 @@ struct DecState {
   uint64_t win_lo, win_hi;
   uint32_t win_final;
   uint32_t *cache;        // 1 << kMaxCacheBits entries
-  // scratch
-  TableScratch ts;
-  HuffTable cl;
-  uint16_t cl_sorted[kNumClSyms];
-  uint8_t lengths[kMaxAlphabet];
+  uint16_t *sorted_multi; // multi_cap * kSortedPerGroup entries for groups_multi
+  DecTableScratch *tsc;   // only used while a code is being read: may share memory with anything the pixel phases own
 };
 
 // What the device driver adds around the machine; all null on the host.
@@ -251,8 +256,12 @@ constexpr uint32_t kWinPixelSlack = 64;   // bytes one token can need at most, w
 constexpr uint32_t kWinPhaseSlack = 1024;
 
 VP8L_HD void dec_init(DecState &st, const uint8_t *data, uint64_t len, uint32_t *out, uint32_t *aux, uint64_t aux_cap,
-                      GroupTables *groups1, GroupTables *groups_multi, uint32_t multi_cap, uint32_t *cache) {
+                      GroupTables *groups1, GroupTables *groups_multi, uint32_t multi_cap, uint32_t *cache,
+                      DecTableScratch *tsc, uint16_t *sorted /* (multi_cap + 1) * kSortedPerGroup */) {
   st.cache = cache; st.win_lo = st.win_hi = 0; st.win_final = 0;
+  st.tsc = tsc;
+  groups1->sorted = sorted;
+  st.sorted_multi = sorted + kSortedPerGroup;
   st.data = data; st.len = len; st.out = out; st.aux = aux; st.aux_cap = aux_cap;
   st.groups = groups1; st.groups1 = groups1; st.groups_multi = groups_multi; st.multi_cap = multi_cap;
   st.bytepos = 0; st.buf = 0; st.cnt = 0;
@@ -271,13 +280,14 @@ VP8L_HD int read_code(BitSrc &br, int alphabet, HuffTable &t, uint16_t *sorted, 
     const uint32_t s1 = nsym == 2 ? br.get(8) : 0;
     return build_simple(t, sorted + t.sorted_off, nsym, s0, s1, alphabet);
   }
-  uint8_t *cl_len = st.lengths;  // first used for the 68 code-length-code lengths
+  DecTableScratch &sc = *st.tsc;
+  uint8_t *cl_len = sc.lengths;  // first used for the 68 code-length-code lengths
   for (int i = 0; i < kNumClSyms; i++) cl_len[i] = 0;
   const uint32_t ncodes = br.get(kClCountBits) + 4;
   if (ncodes > (uint32_t)kNumClSyms) return kErrInvalidHuffman;
   for (uint32_t i = 0; i < ncodes; i++) cl_len[cl_order((int)i)] = (uint8_t)br.get(kClLenBits);
-  st.cl.sorted_off = 0;
-  int rc = build_table(st.cl, st.cl_sorted, cl_len, kNumClSyms, st.ts);
+  sc.cl.sorted_off = 0;
+  int rc = build_table(sc.cl, sc.cl_sorted, cl_len, kNumClSyms, sc.ts);
   if (rc < 0) return rc;
   uint32_t max_symbol;
   if (br.get(1)) {
@@ -287,12 +297,12 @@ VP8L_HD int read_code(BitSrc &br, int alphabet, HuffTable &t, uint16_t *sorted, 
   } else {
     max_symbol = (uint32_t)alphabet;
   }
-  uint8_t *lengths = st.lengths;
+  uint8_t *lengths = sc.lengths;
   for (int i = 0; i < alphabet; i++) lengths[i] = 0;
   int sym = 0, prev = 8;
   while (sym < alphabet) {
     if (max_symbol-- == 0) break;
-    const uint32_t c = read_sym(br, st.cl, st.cl_sorted);
+    const uint32_t c = read_sym(br, sc.cl, sc.cl_sorted);
     if (c < (uint32_t)kClRepeat) {
       lengths[sym++] = (uint8_t)c;
       if (c) prev = (int)c;
@@ -306,7 +316,7 @@ VP8L_HD int read_code(BitSrc &br, int alphabet, HuffTable &t, uint16_t *sorted, 
       for (int i = 0; i < reps; i++) lengths[sym++] = (uint8_t)v;
     }
   }
-  return build_table(t, sorted + t.sorted_off, lengths, alphabet, st.ts);
+  return build_table(t, sorted + t.sorted_off, lengths, alphabet, sc.ts);
 }
 
 // Five codes of one group (huffman_io.h:200-210).
@@ -545,6 +555,7 @@ VP8L_HD uint32_t dec_step(DecState &st, const DecAccel &acc = DecAccel()) {
         }
         const uint32_t cb = st.main_cache_bits;
         for (uint32_t gi = 0; gi < st.ngroups; gi++) {
+          if (st.ngroups > 1) st.groups[gi].sorted = st.sorted_multi + (size_t)gi * kSortedPerGroup;
           const int rc = read_group(br, st.groups[gi], cb ? 1u << cb : 0u, st);
           if (rc < 0) VP8L_FAIL(rc);
         }
@@ -644,15 +655,18 @@ inline int host_decode(const uint8_t *data, size_t len, uint32_t *argb, size_t c
   uint32_t gcap = 64;
   DecState *st = new DecState;
   uint32_t *cache = new uint32_t[1u << kMaxCacheBits];
+  DecTableScratch *tsc = new DecTableScratch;
   int status;
   for (;;) {
     GroupTables *groups = new GroupTables[gcap + 1];
-    dec_init(*st, data, len, argb, aux, aux_cap, groups, groups + 1, gcap, cache);
+    uint16_t *sorted = new uint16_t[(size_t)(gcap + 1) * kSortedPerGroup];
+    dec_init(*st, data, len, argb, aux, aux_cap, groups, groups + 1, gcap, cache, tsc, sorted);
     st->w = w; st->h = h;
     while (dec_step(*st) == kEvCopy)
       for (uint32_t i = 0; i < st->copy_len; i++) st->dst[st->copy_pos + i] = st->dst[st->copy_pos + i - st->copy_dist];
     status = st->status;
     delete[] groups;
+    delete[] sorted;
     if (status == kErrWorkspace && st->need_groups > gcap) { gcap = st->need_groups; continue; }
     break;
   }
@@ -701,6 +715,7 @@ inline int host_decode(const uint8_t *data, size_t len, uint32_t *argb, size_t c
   *h_out = h;
   delete st;
   delete[] cache;
+  delete tsc;
   delete[] aux;
   return status;
 }

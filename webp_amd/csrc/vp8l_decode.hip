@@ -29,6 +29,7 @@ struct DecImage {  // host-written
   uint32_t *scratch;      // copy of the bundled indices for the colour-indexing inverse
   GroupTables *groups;    // tables for streams with more than one Huffman group
   uint32_t *cache;        // colour cache, 2048 entries
+  uint16_t *sorted;       // (group_cap + 1) * kSortedPerGroup: symbols in code order, read for codes longer than the lookup table
   uint32_t group_cap;
   uint32_t pad;
 };
@@ -274,7 +275,14 @@ __device__ __noinline__ void wave_decode_pixels(VP8L_LDS DecState *st_, const VP
 __global__ __launch_bounds__(64) void k_decode_entropy(const DecImage *__restrict__ imgs, DecResult *__restrict__ res) {
   __shared__ DecState st;
   __shared__ GroupTables g0;
-  __shared__ uint32_t ring[kRingPixels];
+  // the ring is used while pixels are decoded, the table scratch while a code is read: never at the same time
+  // (a coded image's codes are read before its first pixel, and every coded image starts a fresh ring)
+  __shared__ union RingOrScratch {
+    uint32_t ring[kRingPixels];
+    DecTableScratch scratch;
+  } ros;
+  static_assert(sizeof(DecTableScratch) <= sizeof(uint32_t) * kRingPixels, "the scratch fits under the ring");
+  uint32_t *ring = ros.ring;
   __shared__ uint32_t win[kStreamWindow / 4];
   const uint32_t img = blockIdx.x, lane = threadIdx.x;
   const DecImage im = imgs[img];
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(64) void k_decode_entropy(const DecImage *__restric
   acc.driver_pixels = true;
   acc.on = true;
   if (lane == 0) {
-    dec_init(st, im.data, im.len, im.out, im.aux, im.aux_cap, &g0, im.groups, im.group_cap, im.cache);
+    dec_init(st, im.data, im.len, im.out, im.aux, im.aux_cap, &g0, im.groups, im.group_cap, im.cache, &ros.scratch, im.sorted);
     st.w = im.w;
     st.h = im.h;
   }
@@ -454,7 +462,7 @@ struct vp8l_decoder {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
-  DeviceBuffer d_imgs, d_res, d_sbfirst, d_aux, d_scratch, d_groups, d_cache;
+  DeviceBuffer d_imgs, d_res, d_sbfirst, d_aux, d_scratch, d_groups, d_cache, d_sorted;
   double last_seconds = 0;
 };
 
@@ -480,7 +488,7 @@ extern "C" void vp8l_decoder_destroy(vp8l_decoder *d) {
   if (d->stream) (void)hipStreamSynchronize(d->stream);
   if (d->ev0) (void)hipEventDestroy(d->ev0);
   if (d->ev1) (void)hipEventDestroy(d->ev1);
-  DeviceBuffer *bufs[] = {&d->d_imgs, &d->d_res, &d->d_sbfirst, &d->d_aux, &d->d_scratch, &d->d_groups, &d->d_cache};
+  DeviceBuffer *bufs[] = {&d->d_imgs, &d->d_res, &d->d_sbfirst, &d->d_aux, &d->d_scratch, &d->d_groups, &d->d_cache, &d->d_sorted};
   for (auto *b : bufs) b->release();
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
@@ -519,13 +527,15 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
                   d->d_sbfirst.reserve((m + 1) * 4) && d->d_aux.reserve(aux_total * 4) &&
                   d->d_scratch.reserve(scratch_total * 4) &&
                   d->d_groups.reserve((size_t)m * group_cap * sizeof(GroupTables) + 16) &&
-                  d->d_cache.reserve((size_t)m * (4u << kMaxCacheBits));
+                  d->d_cache.reserve((size_t)m * (4u << kMaxCacheBits)) &&
+                  d->d_sorted.reserve((size_t)m * (group_cap + 1) * kSortedPerGroup * 2);
   if (!ok) return VP8L_ERR_NO_MEMORY;
   for (uint32_t k = 0; k < m; k++) {
     imgs[k].aux = d->d_aux.as<uint32_t>() + reinterpret_cast<uintptr_t>(imgs[k].aux);
     imgs[k].scratch = d->d_scratch.as<uint32_t>() + reinterpret_cast<uintptr_t>(imgs[k].scratch);
     imgs[k].groups = d->d_groups.as<GroupTables>() + (size_t)k * group_cap;
     imgs[k].cache = d->d_cache.as<uint32_t>() + ((size_t)k << kMaxCacheBits);
+    imgs[k].sorted = d->d_sorted.as<uint16_t>() + (size_t)k * (group_cap + 1) * kSortedPerGroup;
   }
   hipStream_t s = d->stream;
   auto *dimgs = d->d_imgs.as<DecImage>();
