@@ -122,6 +122,11 @@ void vp8l_decoder_destroy(vp8l_decoder *dec);
  * vp8l_get_info.  d_argb[i]: device pointer receiving width[i]*height[i] pixels. */
 int vp8l_decoder_decode_device(vp8l_decoder *dec, size_t n, const uint8_t *const *d_data, const size_t *len,
                                const uint32_t *width, const uint32_t *height, uint32_t *const *d_argb, int *status);
+/* VP8L_DEC_OPT_THREADS_PER_STREAM: how many threads decode one stream's entropy-coded pixels.  0 or 1024
+ * (default) = one workgroup per stream; 64 = one wave per stream (seven times as many streams in flight, each
+ * several times slower: only faster for thousands of small streams of noisy content).  Identical pixels. */
+enum { VP8L_DEC_OPT_THREADS_PER_STREAM = 1 };
+int vp8l_decoder_set_option(vp8l_decoder *dec, int option, int value);
 
 /* Seconds spent in the device part of the last call on the context (HIP events on the
  * context's stream), and per-kernel-stage seconds for the encoder

@@ -33,6 +33,9 @@ print("  " + "  ".join("%s %.2f" % (k, 1e3 * v) for k, v in ss.items()) + "  (ms
 print("  ns/px: " + "  ".join("%s %.3f" % (k, 1e9 * v / (mp * 1e6)) for k, v in ss.items()))
 
 dec = webp_amd.Decoder()
+for a in sys.argv:
+    if a.startswith("--dec-threads="):
+        dec.set_threads_per_stream(int(a.split("=")[1]))
 d_dec = torch.empty((batch, w * h), dtype=torch.int32, device="cuda")
 args = ([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], [w] * batch, [h] * batch, [d_dec[k].data_ptr() for k in range(batch)])
 for it in range(2):

@@ -338,6 +338,479 @@ __global__ __launch_bounds__(64) void k_decode_entropy(const DecImage *__restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same pixels decoded by a workgroup of 1024 threads: the default form.
+// One wave resolves the literals inside 64 stream bits per round; here a round covers 1024 bits:
+//   1. thread t decodes the token that WOULD start at bit offset t of the span -- a literal (four
+//      symbols) or a back reference (length symbol + extra bits, distance symbol + extra bits), codes
+//      longer than the lookup table included -- from a 64-bit piece of the stream window.  That gives
+//      next[t] = t + bits of the token at t (a sink when the token leaves the span or is one of the
+//      rare things decoded below).
+//   2. the tokens that really start in the span are the chain 0, next[0], next[next[0]], ...  It is
+//      found without a serial walk: jump tables next^(2^k) by pointer doubling (k < 7), then marks
+//      spread from offset 0 with the widest jump first, so 128 tokens are marked in 7 steps.
+//   3. a scan of the marked tokens' pixel counts gives every token its output position.  Literals go
+//      straight into the LDS ring.  Every pixel of the round gets the position its value comes from:
+//      itself (literal), an older pixel, or a pixel of this round that a reference makes; the last kind
+//      is replaced by that pixel's own source until none is left (pointer jumping again: the
+//      reference encoder codes a run as copies of 1, 2, 4, 8 ... pixels, each reading the one before).
+//      Then every pixel is fetched from its source.  A round produces at most 2048 pixels.
+//   4. complete blocks of 64 pixels go from the ring to HBM.
+// What a round cannot start with (a token longer than 64 bits, a code of zero bits, a reference
+// longer than 255) is decoded by wave 0 alone, uniformly, as in the one-wave form.
+// With all 1024 threads busy the workgroup is bound by its CU's instruction issue (16 waves on 4
+// SIMDs), not by latency: what counts is instructions per round.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kWgThreads = 1024;
+constexpr uint32_t kWgWaves = kWgThreads / 64;
+constexpr uint32_t kWgSpan = kWgThreads;      // bit offsets looked at per round, one per thread
+constexpr uint32_t kWgLevels = 7;             // jump tables next^(2^k), k < 7: at most 128 tokens per round
+constexpr uint32_t kWgRing = 4096;            // pixels kept in LDS
+constexpr uint32_t kWgNear = 2048;            // pixels a round may produce = how far back the ring is read
+constexpr uint32_t kWgWindow = 4096;          // stream bytes kept in LDS
+constexpr uint32_t kWgWindowWords = kWgWindow / 4 + 4;  // + what the last offsets of a span read past it
+constexpr uint32_t kWgMaxLen = 255;           // longer references take the uniform path
+constexpr uint32_t kWgOwnCopy = 8;            // references up to this length are copied by their own thread
+constexpr uint32_t kWgSorted = 280 + 3 * 256 + 40;  // code-order symbol lists of the five codes without a colour cache
+constexpr uint32_t kWgLongLens = kSaneCodeLen - kLutBits;  // code lengths above the lookup table: 11..32
+constexpr uint32_t kWgLongBatch = 6;          // lengths compared at once
+constexpr uint32_t kWgLongSlots = 24;         // kWgLongLens rounded up to whole batches
+constexpr uint32_t kWgJumpSteps = 12;         // source chains are at most 2048 long: 11 halvings
+static_assert(kWgSpan + 128 <= kWgWindow * 8 / 2, "a span fits the window with room to move");
+static_assert((1u << kWgLevels) <= kWgSpan, "levels");
+static_assert(kWgLongSlots % kWgLongBatch == 0 && kWgLongSlots >= kWgLongLens, "long-code slots");
+
+struct WgShared {
+  uint32_t srcp[kWgNear];                     // per pixel of the round: the position its value comes from (| kFinal)
+  uint32_t changed[kWgJumpSteps];
+  uint16_t ja[kWgSpan + 2], jb[kWgSpan + 2];  // jump tables (ping-pong); entry kWgSpan is the sink
+  uint8_t mark[kWgSpan + 4];                  // 0: not on the chain, else the step that marked it + 1
+  uint32_t wsum[kWgWaves];
+  // codes longer than the lookup table, per code and length l = kLutBits + 1 + slot:
+  //   lim = the largest 32-bit left-justified stream value whose code is at most l bits long,
+  //   base + (code as a number) = index of the symbol in `sorted`
+  uint32_t lim[kNumCodes][kWgLongSlots];
+  uint32_t base[kNumCodes][kWgLongSlots];
+  uint32_t defer_off, defer_px, end_off, end_px;
+  int32_t status;
+  uint32_t s_bits, s_fill, s_flushed;         // what the uniform path did
+  uint16_t sorted[kWgSorted];                 // symbols in code order
+};
+
+__device__ __forceinline__ void wg_window_load(VP8L_LDS uint32_t *win, const DecImage &im, uint64_t lo, uint32_t tid) {
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(im.data);  // 4-byte aligned; bytes past the end read as zero
+  for (uint32_t i = tid; i < kWgWindowWords; i += kWgThreads) {
+    const uint64_t pos = lo + 4ull * i;
+    uint32_t v = 0;
+    if (pos + 4 <= im.len) v = src[pos >> 2];
+    else for (uint32_t k = 0; k < 4; k++) if (pos + k < im.len) v |= (uint32_t)im.data[pos + k] << (8 * k);
+    win[i] = v;
+  }
+}
+
+// One symbol at bit n of w (64 stream bits) by one thread; false when w does not hold all of it.
+__device__ __forceinline__ bool wg_sym(uint64_t w, uint32_t &n, const VP8L_LDS HuffTable &t, const VP8L_LDS WgShared &sh, uint32_t code,
+                                       uint32_t &sym) {
+  if (n > 64 - kLutBits) return false;
+  const uint32_t bits = (uint32_t)(w >> n);
+  const uint32_t e = t.lut[bits & ((1u << kLutBits) - 1u)];
+  if (e != kLongCode) { n += e & 15u; sym = e >> 4; return true; }
+  // A canonical code read as a left-justified number grows with its length, so the length is 11 + the number
+  // of lengths whose largest value is still below the stream's: a few independent reads instead of a walk.
+  const uint32_t v = __brev(bits);
+  uint32_t slot = 0;
+  for (uint32_t s0 = 0; s0 < kWgLongSlots; s0 += kWgLongBatch) {
+    uint32_t above = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kWgLongBatch; k++) above += v > sh.lim[code][s0 + k] ? 1u : 0u;
+    slot = s0 + above;
+    if (above < kWgLongBatch) break;
+  }
+  const uint32_t l = kLutBits + 1 + slot;
+  if (slot >= kWgLongLens || n + l > 64) return false;
+  sym = sh.sorted[sh.base[code][slot] + (v >> (32 - l))];
+  n += l;
+  return true;
+}
+
+// The token that starts at bit 0 of w: hop = its bits (0: not decodable from w alone), cnt = pixels it
+// makes, val = the pixel (literal) or the distance (ref).
+__device__ __forceinline__ void wg_token(uint64_t w, const VP8L_LDS GroupTables &g, const VP8L_LDS WgShared &sh, uint32_t xsize,
+                                         uint32_t &hop, uint32_t &cnt, uint32_t &val, bool &ref) {
+  hop = 0; cnt = 0; val = 0; ref = false;
+  uint32_t n = 0, S = 0;
+  if (!wg_sym(w, n, g.t[kGreen], sh, kGreen, S)) return;
+  if (S < 256) {
+    uint32_t r = 0, b = 0, a = 0;
+    if (!wg_sym(w, n, g.t[kRed], sh, kRed, r) || !wg_sym(w, n, g.t[kBlue], sh, kBlue, b) || !wg_sym(w, n, g.t[kAlpha], sh, kAlpha, a)) return;
+    val = (a << 24) | (r << 16) | (S << 8) | b;
+    cnt = 1;
+    hop = n;
+  } else if (S < 280) {
+    uint32_t base, nb;
+    prefix_decode_base(S - 256, base, nb);
+    if (n + nb > 64) return;
+    const uint32_t length = base + (nb ? (uint32_t)(w >> n) & ((1u << nb) - 1u) : 0u);
+    n += nb;
+    uint32_t ds = 0;
+    if (!wg_sym(w, n, g.t[kDist], sh, kDist, ds)) return;
+    prefix_decode_base(ds, base, nb);
+    if (n + nb > 64) return;
+    const uint32_t dcode = base + (nb ? (uint32_t)(w >> n) & ((1u << nb) - 1u) : 0u);
+    n += nb;
+    if (length > kWgMaxLen) return;
+    val = code_to_dist(xsize, dcode);
+    cnt = length;
+    ref = true;
+    hop = n;
+  }
+}
+
+__device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, const VP8L_LDS GroupTables *g_, VP8L_LDS uint32_t *ring,
+                                              VP8L_LDS uint32_t *win, VP8L_LDS WgShared *sh_, const DecImage &im, uint32_t tid) {
+  VP8L_LDS DecState &st = *st_;
+  const VP8L_LDS GroupTables &g = *g_;
+  VP8L_LDS WgShared &sh = *sh_;
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  constexpr uint32_t kMask = kWgRing - 1;
+  uint64_t P = st.bytepos * 8 - st.cnt;  // position in the stream, in bits
+  const uint32_t total = (uint32_t)st.total, xsize = st.xsize;
+  uint32_t *dst = st.dst;
+  for (uint32_t i = tid; i < kWgSorted; i += kWgThreads) sh.sorted[i] = g.sorted[i];
+  if (tid < kNumCodes * kWgLongSlots) {
+    const uint32_t c = tid / kWgLongSlots, slot = tid % kWgLongSlots, l = kLutBits + 1 + slot;
+    const VP8L_LDS HuffTable &t = g.t[c];
+    uint32_t lim = 0xffffffffu, base = 0;
+    if (l <= t.maxlen) {
+      lim = (uint32_t)(((uint64_t)(t.first[l] + t.count[l]) << (32 - l)) - 1ull);  // not zero: some code is at most 9 bits long
+      base = t.sorted_off + t.index[l] - t.first[l];
+    }
+    sh.lim[c][slot] = lim;
+    sh.base[c][slot] = base;
+  }
+  uint32_t fill = 0, flushed = 0;  // flushed: multiple of 64, everything before it is in HBM
+  uint64_t win_bit0 = 0;
+  bool have_window = false;
+  int32_t status = kOk;
+  if (tid == 0) {
+    sh.status = kOk;
+    sh.ja[kWgSpan] = (uint16_t)kWgSpan;
+    sh.jb[kWgSpan] = (uint16_t)kWgSpan;
+  }
+  while (fill < total) {
+    if (!have_window || P < win_bit0 || P + kWgSpan + 128 > win_bit0 + kWgWindow * 8) {
+      __syncthreads();
+      const uint64_t lo = (P >> 3) & ~3ull;
+      wg_window_load(win, im, lo, tid);
+      win_bit0 = lo * 8;
+      have_window = true;
+    }
+    __syncthreads();
+    // ---- 1. the token that would start at offset tid
+    uint32_t hop, cnt, val;
+    bool ref;
+    {
+      const uint32_t a = (uint32_t)(P - win_bit0) + tid, idx = a >> 5, sft = a & 31u;
+      const uint64_t x = (uint64_t)win[idx] | ((uint64_t)win[idx + 1] << 32);
+      const uint64_t w = sft ? (x >> sft) | ((uint64_t)win[idx + 2] << (64 - sft)) : x;
+      wg_token(w, g, sh, xsize, hop, cnt, val, ref);
+    }
+    uint32_t j[kWgLevels];
+    j[0] = hop && tid + hop < kWgSpan ? tid + hop : kWgSpan;
+    sh.ja[tid] = (uint16_t)j[0];
+    sh.mark[tid] = tid == 0 ? (uint8_t)(kWgLevels + 1) : (uint8_t)0;
+    // ---- 2. jump tables, then the marks
+    VP8L_LDS uint16_t *cur = sh.ja, *oth = sh.jb;
+#pragma unroll
+    for (uint32_t k = 1; k < kWgLevels; k++) {
+      __syncthreads();
+      j[k] = cur[j[k - 1]];
+      oth[tid] = (uint16_t)j[k];
+      VP8L_LDS uint16_t *t16 = cur; cur = oth; oth = t16;
+    }
+    uint32_t beyond = kWgSpan;  // thread 0: where the 129th token starts, if the chain is that long
+#pragma unroll
+    for (int k = (int)kWgLevels - 1; k >= 0; k--) {
+      __syncthreads();
+      if (k == (int)kWgLevels - 1 && tid == 0) beyond = cur[cur[0]];
+      // only marks older than this step spread: a mark set during the step (value k + 1) does not
+      if (sh.mark[tid] > (uint32_t)k + 1) sh.mark[j[k]] = (uint8_t)(k + 1);
+    }
+    __syncthreads();
+    const bool on = sh.mark[tid] != 0;
+    // ---- 3. output positions
+    const uint32_t c = on && hop ? cnt : 0u;
+    const uint32_t incl = wave_incl_scan_u32(c, (int)lane);
+    if (lane == 63) sh.wsum[wave] = incl;
+    if (tid == 0) { sh.defer_off = 0xffffffffu; sh.end_off = 0; sh.end_px = 0; }
+    __syncthreads();
+    // the waves' sums, scanned by every wave for itself
+    const uint32_t wsums = wave_incl_scan_u32(lane < kWgWaves ? sh.wsum[lane] : 0u, (int)lane);
+    const uint32_t before = wave ? lane_read(wsums, wave - 1) : 0u, all = lane_read(wsums, kWgWaves - 1);
+    const uint32_t ex = before + incl - c;
+    const uint32_t left = total - fill, room = left < kWgNear ? left : kWgNear;
+    if (tid == 0 && beyond != kWgSpan) { sh.end_off = beyond; sh.end_px = all; }
+    // Literals go to the ring.  Every pixel of the round gets a source: itself (literal: final), an older pixel
+    // (final), or a pixel of this round that a reference makes (to be followed further).
+    constexpr uint32_t kFinal = 0x80000000u;
+    bool expand = false;  // a reference of this round whose pixels get their sources
+    const uint32_t pos = fill + ex;
+    if (on) {
+      if (hop == 0) {
+        sh.end_off = tid;  // the chain ends at something this round cannot decode
+        sh.end_px = ex;
+      } else {
+        if (j[0] == kWgSpan) { sh.end_off = tid + hop; sh.end_px = ex + cnt; }
+        if (ex + cnt > room) {
+          if (ex <= room) {  // the first token that does not fit: the next round starts with it
+            sh.defer_off = tid;
+            sh.defer_px = ex;
+            if (room == left && ex < room) sh.status = kErrInvalidVp8l;  // a reference that runs past the end of the image
+          }
+        } else if (!ref) {
+          ring[pos & kMask] = val;
+          sh.srcp[ex] = pos | kFinal;
+        } else if (val > pos) {
+          // The reference copies without checking (vp8l.h:298-300); a reference before the start of the image is reported.
+          sh.status = kErrInvalidVp8l;
+        } else {
+          expand = true;
+        }
+      }
+    }
+    if (expand && cnt <= kWgOwnCopy) {
+      if (val >= cnt) {
+        for (uint32_t e = 0; e < cnt; e++) {
+          const uint32_t s = pos - val + e;
+          sh.srcp[ex + e] = s < fill ? s | kFinal : s;
+        }
+      } else {  // overlapping: the first `val` pixels repeat
+        for (uint32_t e = 0; e < cnt; e++) {
+          const uint32_t s = pos - val + e % val;
+          sh.srcp[ex + e] = s < fill ? s | kFinal : s;
+        }
+      }
+    }
+    {
+      uint64_t m = __ballot(expand && cnt > kWgOwnCopy);  // the longer ones: the wave writes 64 sources at a time
+      while (m) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t p2 = lane_read(pos, l), n = lane_read(cnt, l), dist = lane_read(val, l), x2 = lane_read(ex, l);
+        for (uint32_t c2 = 0; c2 < n; c2 += 64) {
+          const uint32_t e = c2 + lane;
+          if (e < n) {
+            uint32_t s = p2 - dist + e;
+            if (dist < n) s = p2 - dist + e % dist;  // uniform
+            sh.srcp[x2 + e] = s < fill ? s | kFinal : s;
+          }
+        }
+      }
+    }
+    if (tid < kWgJumpSteps) sh.changed[tid] = 0;
+    __syncthreads();
+    status = sh.status;
+    if (status != kOk) break;
+    const bool deferred = sh.defer_off != 0xffffffffu;
+    const uint32_t adv = deferred ? sh.defer_off : sh.end_off, produced = deferred ? sh.defer_px : sh.end_px;
+    // Sources that are made by a reference of this round are replaced by that pixel's source until every pixel
+    // points at a final one: chains of references (a run coded as copies of 1, 2, 4, 8 ... pixels) take
+    // log2(chain length) steps instead of one copy after the other.  A source read while its owner replaces
+    // it is the old or the new value; both are sources of the same pixel value.
+    for (uint32_t it = 0; it < kWgJumpSteps; it++) {
+      bool open = false;
+#pragma unroll
+      for (uint32_t k = 0; k < kWgNear / kWgThreads; k++) {
+        const uint32_t q = k * kWgThreads + tid;
+        if (q < produced) {
+          const uint32_t v = sh.srcp[q];
+          if (!(v & kFinal)) {
+            const uint32_t t = sh.srcp[v - fill];
+            sh.srcp[q] = t;
+            open = open || !(t & kFinal);
+          }
+        }
+      }
+      if (open) sh.changed[it] = 1;
+      __syncthreads();
+      if (!sh.changed[it]) break;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kWgNear / kWgThreads; k++) {
+      const uint32_t q = k * kWgThreads + tid;
+      if (q < produced) {
+        const uint32_t s = sh.srcp[q] & ~kFinal;
+        if (s != fill + q) ring[(fill + q) & kMask] = s + kWgNear >= fill ? ring[s & kMask] : dst[s];
+      }
+    }
+    __syncthreads();
+    fill += produced;
+    P += adv;
+    {
+      const uint32_t upto = fill & ~63u;
+      for (uint32_t p = flushed + tid; p < upto; p += kWgThreads) dst[p] = ring[p & kMask];
+      flushed = upto;
+    }
+    if (adv == 0 && produced == 0) {
+      // ---- the token at P is one a round cannot decode: wave 0 decodes it uniformly
+      if (wave == 0) {
+        __threadfence_block();
+        const uint32_t a = (uint32_t)(P - win_bit0), idx = a >> 5, sft = a & 31u;
+        const uint64_t x = (uint64_t)uni(win[idx]) | ((uint64_t)uni(win[idx + 1]) << 32);
+        const uint64_t y = (uint64_t)uni(win[idx + 2]) | ((uint64_t)uni(win[idx + 3]) << 32);
+        const uint64_t z = (uint64_t)uni(win[idx + 4]);
+        WaveBits b;
+        b.lo = sft ? (x >> sft) | (y << (64 - sft)) : x;
+        b.hi = sft ? (y >> sft) | (z << (64 - sft)) : y;
+        b.cnt = 128;
+        b.widx = 0;
+        b.win_lo = 0;
+        const VP8L_LDS uint16_t *sorted = sh.sorted;
+        uint32_t nfill = fill, nflushed = flushed;
+        int32_t rc = kOk;
+        const uint32_t S = wb_sym(b, g.t[kGreen], sorted, lane);
+        if (S < 256) {
+          const uint32_t r2 = wb_sym(b, g.t[kRed], sorted, lane);
+          const uint32_t b2 = wb_sym(b, g.t[kBlue], sorted, lane);
+          const uint32_t a2 = wb_sym(b, g.t[kAlpha], sorted, lane);
+          if (lane == 0) ring[fill & kMask] = (a2 << 24) | (r2 << 16) | (S << 8) | b2;
+          nfill = fill + 1;
+        } else if (S < 280) {
+          uint32_t base, nb;
+          prefix_decode_base(S - 256, base, nb);
+          const uint32_t length = base + wb_get(b, nb);
+          prefix_decode_base(wb_sym(b, g.t[kDist], sorted, lane), base, nb);
+          const uint32_t dcode = base + wb_get(b, nb);
+          const uint32_t dist = code_to_dist(xsize, dcode);
+          if (dist > fill || length > total - fill) {
+            rc = kErrInvalidVp8l;
+          } else {
+            // in pieces of 1024 pixels, each flushed before the next, so the ring never wraps onto what is still read
+            for (uint32_t c0 = 0; c0 < length; c0 += 1024) {
+              const uint32_t piece = length - c0 < 1024 ? length - c0 : 1024, start = fill + c0;
+              for (uint32_t c2 = 0; c2 < piece; c2 += 64) {
+                const uint32_t e = c0 + c2 + lane;
+                if (c2 + lane < piece) {
+                  const uint32_t s = fill - dist + (dist >= length ? e : e % dist);
+                  ring[(fill + e) & kMask] = s + kWgNear >= start ? ring[s & kMask] : dst[s];
+                }
+              }
+              const uint32_t upto = (start + piece) & ~63u;
+              while (nflushed < upto) {
+                dst[nflushed + lane] = ring[(nflushed + lane) & kMask];
+                nflushed += 64;
+              }
+              __threadfence_block();
+            }
+            nfill = fill + length;
+          }
+        } else {
+          rc = kErrInvalidVp8l;  // no colour cache: no such symbol in a 280-symbol alphabet
+        }
+        if (lane == 0) {
+          sh.s_bits = 128 - b.cnt;
+          sh.s_fill = nfill;
+          sh.s_flushed = nflushed;
+          if (rc != kOk) sh.status = rc;
+        }
+      }
+      __syncthreads();
+      P += sh.s_bits;
+      fill = sh.s_fill;
+      flushed = sh.s_flushed;
+      status = sh.status;
+      if (status != kOk) break;
+      const uint32_t upto = fill & ~63u;
+      for (uint32_t p = flushed + tid; p < upto; p += kWgThreads) dst[p] = ring[p & kMask];
+      flushed = upto;
+    }
+  }
+  if (status == kOk)
+    for (uint32_t p = flushed + tid; p < fill; p += kWgThreads) dst[p] = ring[p & kMask];
+  __threadfence_block();
+  if (tid == 0) {
+    // hand the reader back as the machine keeps it: the next unread word, and the bits of the current one
+    BitSrc src;
+    src.init(im.data, im.len);
+    const uint64_t word = (P >> 5) * 4;
+    const uint32_t used = (uint32_t)(P & 31u);
+    st.fill = fill;
+    st.bytepos = used ? word + 4 : word;
+    st.cnt = used ? 32 - used : 0;
+    st.buf = used ? (uint64_t)(src.load32(word) >> used) : 0ull;
+    st.win_lo = 0;
+    st.win_hi = 0;
+    st.win_final = 0;
+    if (status == kOk) st.phase = st.after;
+    else { st.status = status; st.phase = kPhDone; }
+  }
+}
+
+__global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage *__restrict__ imgs, DecResult *__restrict__ res) {
+  __shared__ DecState st;
+  __shared__ GroupTables g0;
+  // the ring is used while pixels are decoded, the table scratch while a code is read: never at the same time
+  __shared__ union RingOrScratch {
+    uint32_t ring[kWgRing];
+    DecTableScratch scratch;
+  } ros;
+  static_assert(sizeof(DecTableScratch) <= sizeof(uint32_t) * kWgRing, "the scratch fits under the ring");
+  __shared__ uint32_t win[kWgWindowWords];
+  __shared__ __attribute__((aligned(16))) WgShared sh;
+  __shared__ uint32_t s_ev;
+  const uint32_t img = blockIdx.x, tid = threadIdx.x;
+  const DecImage im = imgs[img];
+  DecAccel acc;
+  acc.win = win;
+  acc.win_bytes = kWgWindow;
+  acc.ring = ros.ring;
+  acc.ring_mask = kWgRing - 1;
+  acc.g0 = &g0;
+  acc.driver_pixels = true;
+  acc.on = true;
+  if (tid == 0) {
+    dec_init(st, im.data, im.len, im.out, im.aux, im.aux_cap, &g0, im.groups, im.group_cap, im.cache, &ros.scratch, im.sorted);
+    st.w = im.w;
+    st.h = im.h;
+  }
+  __syncthreads();
+  for (;;) {
+    if (tid == 0) s_ev = dec_step(st, acc);
+    __syncthreads();  // the request, lane 0's LDS state and its pixel stores before the others act on them
+    const uint32_t ev = s_ev;
+    if (ev == kEvDone) break;
+    if (ev == kEvPixels) {
+      wg_decode_pixels((VP8L_LDS DecState *)&st, (const VP8L_LDS GroupTables *)&g0, (VP8L_LDS uint32_t *)ros.ring,
+                       (VP8L_LDS uint32_t *)win, (VP8L_LDS WgShared *)&sh, im, tid);
+    } else if (ev == kEvRefill) {
+      const uint64_t lo = st.bytepos;
+      wg_window_load((VP8L_LDS uint32_t *)win, im, lo, tid);
+      if (tid == 0) { st.win_lo = lo; st.win_hi = lo + kWgWindow; st.win_final = lo + kWgWindow >= im.len; }
+    } else {
+      __threadfence_block();
+      uint32_t *dst = st.dst;
+      const uint64_t pos = st.copy_pos;
+      const uint32_t dist = st.copy_dist, len = st.copy_len;
+      // pixel i of the copy equals pixel (i mod dist) of the source window: correct for overlapping
+      // references too, and every source is already final (in HBM: lane 0 stores every pixel there too)
+      for (uint32_t i = tid; i < len; i += kWgThreads) {
+        const uint32_t v = dst[pos - dist + (dist >= len ? i : i % dist)];
+        dst[pos + i] = v;
+        if (i + kWgRing >= len) ros.ring[(uint32_t)(pos + i) & (kWgRing - 1)] = v;
+      }
+      __threadfence_block();
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    DecResult &r = res[img];
+    r.status = st.status;
+    r.need_groups = st.need_groups;
+    r.nxf = st.nxf;
+    for (uint32_t k = 0; k < 4; k++) r.xf[k] = st.xf[k];
+  }
+}
+
 // Which transform this pass undoes for an image: pass k undoes the (k+1)-th from the end.
 __device__ __forceinline__ bool pass_transform(const DecResult &r, uint32_t pass, XformRec &x) {
   if (r.status != 0 || pass >= r.nxf) return false;
@@ -464,7 +937,18 @@ struct vp8l_decoder {
   std::mutex mu;
   DeviceBuffer d_imgs, d_res, d_sbfirst, d_aux, d_scratch, d_groups, d_cache, d_sorted;
   double last_seconds = 0;
+  int threads_per_stream = 0;  // 0: chosen per call
 };
+
+extern "C" int vp8l_decoder_set_option(vp8l_decoder *d, int option, int value) {
+  if (!d) return VP8L_ERR_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lock(d->mu);
+  if (option == VP8L_DEC_OPT_THREADS_PER_STREAM && (value == 0 || value == 64 || value == (int)kWgThreads)) {
+    d->threads_per_stream = value;
+    return VP8L_OK;
+  }
+  return VP8L_ERR_BAD_ARGUMENT;
+}
 
 extern "C" int vp8l_decoder_create(int device, vp8l_decoder **out) {
   if (!out) return VP8L_ERR_BAD_ARGUMENT;
@@ -547,7 +1031,10 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
     return VP8L_ERR_HIP;
   const uint32_t gunits = (uint32_t)(sb_total * kUnitsPerSuper);
   (void)hipEventRecord(d->ev0, s);
-  hipLaunchKernelGGL(k_decode_entropy, dim3(m), dim3(64), 0, s, dimgs, dres);
+  // A workgroup per stream decodes one stream several times faster than a wave per stream; the waves only win
+  // with thousands of small streams of noisy content, so they are an option, not the default.
+  if (d->threads_per_stream == 64) hipLaunchKernelGGL(k_decode_entropy, dim3(m), dim3(64), 0, s, dimgs, dres);
+  else hipLaunchKernelGGL(k_decode_entropy_wg, dim3(m), dim3(kWgThreads), 0, s, dimgs, dres);
   for (uint32_t pass = 0; pass < 4; pass++) {
     hipLaunchKernelGGL(k_inverse_stash, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m, pass);
     hipLaunchKernelGGL(k_inverse_pointwise, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m, pass);
