@@ -49,7 +49,7 @@ def main():
             for k in range(batch):
                 L.vp8l_free(C.c_void_p(outs[k]))
     # decode the streams of the last pass
-    for rep in range(2):
+    for rep in range(0 if "--no-decode" in sys.argv else 2):
         argb = (C.c_void_p * batch)()
         ow = (C.c_uint32 * batch)()
         oh = (C.c_uint32 * batch)()

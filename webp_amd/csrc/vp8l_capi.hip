@@ -1,12 +1,15 @@
 // vp8l_capi.hip -- host-memory entry points of the C ABI (include/vp8l_amd.h) and shared host
-// helpers.  The host-memory forms stage images through HBM and call the device-memory batch
-// forms; all codec work happens in the kernels of vp8l_encode.hip / vp8l_decode.hip.
+// helpers.  The host-memory forms stage images through HBM in chunks, overlapping uploads, kernels and
+// downloads on separate HIP streams, and call the device-memory batch forms; all codec work happens in
+// the kernels of vp8l_encode.hip / vp8l_decode.hip.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "vp8l_amd.h"
@@ -51,62 +54,128 @@ int select_device(int device, int *chosen) {
 
 namespace {
 
-// One shared context pair per device for the host-memory entry points.
+// The host-memory entry points cut a batch into chunks and run them through a few lanes per device.  A lane
+// owns an encoder or decoder context (with its HIP stream and workspace), staging buffers in HBM and a copy
+// stream; a host thread per lane uploads a chunk, runs the kernels and downloads the results, so the upload of
+// one chunk, the kernels of another and the download of a third overlap (copy engines and CUs work side by
+// side).  Staging buffers are kept between calls (grow-only): hipMalloc / hipFree synchronise the device.
+// Measured on a 128 x 3840x2160 batch from page-locked memory: 3 lanes x 128 MiB move 22 GB/s, 8 x 64 MiB 35 GB/s,
+// 12 x 64 MiB 39 GB/s (the link does 57 GB/s one way); VP8L_HOST_LANES / VP8L_HOST_CHUNK_MB override the defaults.
+constexpr int kLanes = 16;  // at most
+int env_int(const char *name, int fallback, int lo, int hi) {
+  const char *v = getenv(name);
+  if (!v) return fallback;
+  const int x = atoi(v);
+  return x < lo ? lo : x > hi ? hi : x;
+}
+const int g_lanes = env_int("VP8L_HOST_LANES", 8, 1, kLanes);
+const size_t g_chunk_bytes = (size_t)env_int("VP8L_HOST_CHUNK_MB", 64, 1, 4096) << 20;  // pixel bytes per encode chunk (at least one image)
+// The decoder runs one workgroup per stream and a stream takes as long as it takes: a chunk should hold enough
+// streams to fill the device, so chunks close at 256 streams (and at least the encode chunk size), or at 8 GiB of pixels.
+constexpr size_t kDecodeChunkStreams = 256;
+constexpr size_t kDecodeChunkMaxBytes = (size_t)8 << 30;
+
+struct Lane {
+  vp8l_encoder *enc = nullptr;
+  vp8l_decoder *dec = nullptr;
+  hipStream_t copy = nullptr;
+  DeviceBuffer d_in, d_out;
+};
+
+struct Pipeline {
+  std::mutex mu;  // one host-memory call at a time per pipeline
+  int device = 0;
+  Lane lanes[kLanes];
+};
+
 struct HostContexts {
   std::mutex mu;
-  std::map<int, vp8l_encoder *> enc;
-  std::map<int, vp8l_decoder *> dec;
+  std::map<int, Pipeline *> enc;  // key: device * 16 + predictor setting (callers with different flags never share option state)
+  std::map<int, Pipeline *> dec;  // key: device
 };
 HostContexts &contexts() {
   static HostContexts *c = new HostContexts;  // intentionally leaked: HIP may be gone at exit
   return *c;
 }
 
-// one shared context per (device, predictor setting): callers with different flags never share option state
-int get_encoder(int device, int pred_bits, vp8l_encoder **e) {
+int get_pipeline(bool encoder, int device, int pred_bits, Pipeline **out) {
   int dev = device;
   int rc = select_device(device, &dev);
   if (rc != VP8L_OK) return rc;
   HostContexts &c = contexts();
   std::lock_guard<std::mutex> lock(c.mu);
-  const int key = dev * 16 + pred_bits;
-  auto it = c.enc.find(key);
-  if (it == c.enc.end()) {
-    vp8l_encoder *ne = nullptr;
-    rc = vp8l_encoder_create(dev, &ne);
+  std::map<int, Pipeline *> &m = encoder ? c.enc : c.dec;
+  const int key = encoder ? dev * 16 + pred_bits : dev;
+  auto it = m.find(key);
+  if (it == m.end()) {
+    Pipeline *p = new (std::nothrow) Pipeline;
+    if (!p) return VP8L_ERR_NO_MEMORY;
+    p->device = dev;
+    it = m.emplace(key, p).first;
+  }
+  *out = it->second;
+  return VP8L_OK;
+}
+
+// Creates what a lane needs on first use (the pipeline's mutex is held).
+int lane_ready(Pipeline *p, Lane &l, bool encoder, int pred_bits) {
+  if (!l.copy && !hip_ok(hipStreamCreateWithFlags(&l.copy, hipStreamNonBlocking), "hipStreamCreate")) return VP8L_ERR_HIP;
+  if (encoder && !l.enc) {
+    int rc = vp8l_encoder_create(p->device, &l.enc);
     if (rc != VP8L_OK) return rc;
-    if (pred_bits && vp8l_encoder_set_option(ne, VP8L_OPT_PREDICTOR_BITS, pred_bits) != VP8L_OK) {
-      vp8l_encoder_destroy(ne);
-      return VP8L_ERR_BAD_ARGUMENT;
+    if (pred_bits && vp8l_encoder_set_option(l.enc, VP8L_OPT_PREDICTOR_BITS, pred_bits) != VP8L_OK) return VP8L_ERR_BAD_ARGUMENT;
+  }
+  if (!encoder && !l.dec) {
+    int rc = vp8l_decoder_create(p->device, &l.dec);
+    if (rc != VP8L_OK) return rc;
+  }
+  return VP8L_OK;
+}
+
+// Consecutive items [first[k], first[k+1]) form chunk k.  A chunk is closed before an item that would take it past
+// `soft` bytes once it holds `min_items`, and in any case before one that would take it past `hard` bytes; it
+// always holds at least one item.
+std::vector<size_t> make_chunks(const std::vector<size_t> &bytes, size_t min_items, size_t soft, size_t hard) {
+  std::vector<size_t> first(1, 0);
+  size_t acc = 0, count = 0;
+  for (size_t i = 0; i < bytes.size(); i++) {
+    if (count && ((count >= min_items && acc + bytes[i] > soft) || acc + bytes[i] > hard)) { first.push_back(i); acc = 0; count = 0; }
+    acc += bytes[i];
+    count++;
+  }
+  first.push_back(bytes.size());
+  return first;
+}
+
+// Runs work(lane, chunk) for every chunk on up to kLanes host threads; returns the first failure.
+template <class Work>
+int run_chunks(Pipeline *p, size_t nchunks, Work work) {
+  std::atomic<size_t> next(0);
+  std::atomic<int> failure(VP8L_OK);
+  std::string failure_text;
+  std::mutex text_mu;
+  auto body = [&](int lane) {
+    if (hipSetDevice(p->device) != hipSuccess) { failure = VP8L_ERR_HIP; return; }
+    for (;;) {
+      const size_t c = next.fetch_add(1);
+      if (c >= nchunks || failure.load() != VP8L_OK) return;
+      const int rc = work(p->lanes[lane], c);
+      if (rc != VP8L_OK) {
+        (void)hipStreamSynchronize(p->lanes[lane].copy);  // no copy may still write into buffers the caller is about to free
+        std::lock_guard<std::mutex> lock(text_mu);
+        if (failure.load() == VP8L_OK) { failure = rc; failure_text = last_error_slot(); }  // the text is per thread: carry it over
+        return;
+      }
     }
-    it = c.enc.emplace(key, ne).first;
-  }
-  *e = it->second;
-  return VP8L_OK;
+  };
+  const int nthreads = (int)std::min<size_t>(g_lanes, nchunks);
+  std::vector<std::thread> threads;
+  for (int t = 1; t < nthreads; t++) threads.emplace_back(body, t);
+  body(0);
+  for (auto &t : threads) t.join();
+  if (failure.load() != VP8L_OK) last_error_slot() = failure_text;
+  return failure.load();
 }
-
-int get_decoder(int device, vp8l_decoder **d) {
-  int dev = device;
-  int rc = select_device(device, &dev);
-  if (rc != VP8L_OK) return rc;
-  HostContexts &c = contexts();
-  std::lock_guard<std::mutex> lock(c.mu);
-  auto it = c.dec.find(dev);
-  if (it == c.dec.end()) {
-    vp8l_decoder *nd = nullptr;
-    rc = vp8l_decoder_create(dev, &nd);
-    if (rc != VP8L_OK) return rc;
-    it = c.dec.emplace(dev, nd).first;
-  }
-  *d = it->second;
-  return VP8L_OK;
-}
-
-struct DevMem {
-  void *p = nullptr;
-  ~DevMem() { if (p) (void)hipFree(p); }
-  bool alloc(size_t bytes) { return hip_ok(hipMalloc(&p, bytes ? bytes : 4), "hipMalloc"); }
-};
 
 }  // namespace
 }  // namespace vp8l
@@ -166,45 +235,60 @@ int encode_batch_with(int device, int pred_bits, size_t n, const uint32_t *const
                       const uint32_t *height, uint8_t **out, size_t *out_len, int *status) {
   if (!argb || !width || !height || !out || !out_len || !status) return VP8L_ERR_BAD_ARGUMENT;
   if (n == 0) return VP8L_OK;
-  vp8l_encoder *e = nullptr;
-  int rc = get_encoder(device, pred_bits, &e);
+  Pipeline *p = nullptr;
+  int rc = get_pipeline(true, device, pred_bits, &p);
   if (rc != VP8L_OK) return rc;
-  // stage inputs in one device buffer, outputs in another
-  std::vector<size_t> in_off(n, 0);
-  std::vector<const uint32_t *> d_ptrs(n, nullptr);
-  size_t in_total = 0, out_total = 0;
+  std::lock_guard<std::mutex> lock(p->mu);
+  std::vector<size_t> bytes(n, 0);
   for (size_t i = 0; i < n; i++) {
     out[i] = nullptr;
     out_len[i] = 0;
+    status[i] = VP8L_OK;
     const bool valid = argb[i] && width[i] && height[i] && width[i] <= kMaxDim && height[i] <= kMaxDim;
-    if (!valid) continue;
-    in_off[i] = in_total;
-    in_total += (((size_t)width[i] * height[i] * 4) + 255) & ~(size_t)255;
-    out_total += vp8l_encode_bound(width[i], height[i]);
+    if (valid) bytes[i] = (size_t)width[i] * height[i] * 4;
   }
-  DevMem d_in, d_out;
-  if (!d_in.alloc(in_total) || !d_out.alloc(out_total)) return VP8L_ERR_NO_MEMORY;
-  for (size_t i = 0; i < n; i++) {
-    const bool valid = argb[i] && width[i] && height[i] && width[i] <= kMaxDim && height[i] <= kMaxDim;
-    if (!valid) { d_ptrs[i] = argb[i] ? reinterpret_cast<const uint32_t *>(d_in.p) : nullptr; continue; }
-    uint8_t *dst = static_cast<uint8_t *>(d_in.p) + in_off[i];
-    if (!hip_ok(hipMemcpy(dst, argb[i], (size_t)width[i] * height[i] * 4, hipMemcpyHostToDevice), "upload image")) return VP8L_ERR_HIP;
-    d_ptrs[i] = reinterpret_cast<const uint32_t *>(dst);
-  }
-  std::vector<size_t> off(n, 0);
-  rc = vp8l_encoder_encode_device(e, n, d_ptrs.data(), width, height, static_cast<uint8_t *>(d_out.p), out_total, off.data(), out_len, status);
-  if (rc != VP8L_OK) return rc;
-  for (size_t i = 0; i < n; i++) {
-    if (status[i] != VP8L_OK) { out_len[i] = 0; continue; }
-    out[i] = static_cast<uint8_t *>(malloc(out_len[i] ? out_len[i] : 1));
-    if (!out[i]) { status[i] = VP8L_ERR_NO_MEMORY; continue; }
-    if (!hip_ok(hipMemcpy(out[i], static_cast<uint8_t *>(d_out.p) + off[i], out_len[i], hipMemcpyDeviceToHost), "download stream")) {
-      free(out[i]);
-      out[i] = nullptr;
-      return VP8L_ERR_HIP;
+  const std::vector<size_t> first = make_chunks(bytes, 1, g_chunk_bytes, g_chunk_bytes);
+  for (int l = 0; l < g_lanes && l < (int)first.size() - 1; l++)
+    if ((rc = lane_ready(p, p->lanes[l], true, pred_bits)) != VP8L_OK) return rc;
+  auto work = [&](Lane &lane, size_t c) -> int {
+    const size_t i0 = first[c], m = first[c + 1] - i0;
+    std::vector<size_t> in_off(m, 0);
+    size_t in_total = 0, out_total = 0;
+    for (size_t k = 0; k < m; k++) {
+      in_off[k] = in_total;
+      in_total += (bytes[i0 + k] + 255) & ~(size_t)255;
+      if (bytes[i0 + k]) out_total += vp8l_encode_bound(width[i0 + k], height[i0 + k]);
     }
+    if (!lane.d_in.reserve(in_total + 256) || !lane.d_out.reserve(out_total + 256)) return VP8L_ERR_NO_MEMORY;
+    std::vector<const uint32_t *> d_ptrs(m, nullptr);
+    for (size_t k = 0; k < m; k++) {
+      uint8_t *dst = lane.d_in.as<uint8_t>() + in_off[k];
+      // an invalid image keeps a non-null pointer only if the caller gave one, so the device call reports it the same way
+      d_ptrs[k] = argb[i0 + k] ? reinterpret_cast<const uint32_t *>(dst) : nullptr;
+      if (bytes[i0 + k] && !hip_ok(hipMemcpyAsync(dst, argb[i0 + k], bytes[i0 + k], hipMemcpyHostToDevice, lane.copy), "upload image"))
+        return VP8L_ERR_HIP;
+    }
+    if (!hip_ok(hipStreamSynchronize(lane.copy), "upload images")) return VP8L_ERR_HIP;
+    std::vector<size_t> off(m, 0);
+    const int r = vp8l_encoder_encode_device(lane.enc, m, d_ptrs.data(), width + i0, height + i0, lane.d_out.as<uint8_t>(), out_total + 256,
+                                             off.data(), out_len + i0, status + i0);
+    if (r != VP8L_OK) return r;
+    for (size_t k = 0; k < m; k++) {
+      const size_t i = i0 + k;
+      if (status[i] != VP8L_OK) { out_len[i] = 0; continue; }
+      out[i] = static_cast<uint8_t *>(malloc(out_len[i] ? out_len[i] : 1));
+      if (!out[i]) { status[i] = VP8L_ERR_NO_MEMORY; out_len[i] = 0; continue; }
+      if (!hip_ok(hipMemcpyAsync(out[i], lane.d_out.as<uint8_t>() + off[k], out_len[i], hipMemcpyDeviceToHost, lane.copy), "download stream"))
+        return VP8L_ERR_HIP;
+    }
+    if (!hip_ok(hipStreamSynchronize(lane.copy), "download streams")) return VP8L_ERR_HIP;
+    return VP8L_OK;
+  };
+  rc = run_chunks(p, first.size() - 1, work);
+  if (rc != VP8L_OK) {
+    for (size_t i = 0; i < n; i++) { free(out[i]); out[i] = nullptr; out_len[i] = 0; }
   }
-  return VP8L_OK;
+  return rc;
 }
 }  // namespace
 
@@ -228,60 +312,69 @@ extern "C" int vp8l_decode_batch(int device, size_t n, const uint8_t *const *dat
                                  uint32_t *width, uint32_t *height, int *status) {
   if (!data || !len || !argb || !width || !height || !status) return VP8L_ERR_BAD_ARGUMENT;
   if (n == 0) return VP8L_OK;
-  vp8l_decoder *d = nullptr;
-  int rc = get_decoder(device, &d);
+  Pipeline *p = nullptr;
+  int rc = get_pipeline(false, device, 0, &p);
   if (rc != VP8L_OK) return rc;
-  std::vector<size_t> in_off(n, 0), out_off(n, 0);
-  size_t in_total = 0, out_total = 0;
-  std::vector<char> valid(n, 0);
+  std::lock_guard<std::mutex> lock(p->mu);
+  // streams that already fail here keep their status; the device sees only the others
+  std::vector<size_t> idx, bytes;
   for (size_t i = 0; i < n; i++) {
     argb[i] = nullptr;
     width[i] = height[i] = 0;
     status[i] = data[i] ? vp8l_get_info(data[i], len[i], &width[i], &height[i]) : VP8L_ERR_BAD_ARGUMENT;
     if (status[i] != VP8L_OK) continue;
-    valid[i] = 1;
-    in_off[i] = in_total;
-    in_total += (len[i] + 255 + 8) & ~(size_t)255;
-    out_off[i] = out_total;
-    out_total += (((size_t)width[i] * height[i] * 4) + 255) & ~(size_t)255;
+    idx.push_back(i);
+    bytes.push_back((size_t)width[i] * height[i] * 4);
   }
-  DevMem d_in, d_out;
-  if (!d_in.alloc(in_total) || !d_out.alloc(out_total)) return VP8L_ERR_NO_MEMORY;
-  std::vector<const uint8_t *> d_data(n, nullptr);
-  std::vector<uint32_t *> d_argb(n, nullptr);
-  for (size_t i = 0; i < n; i++) {
-    if (!valid[i]) continue;
-    uint8_t *dst = static_cast<uint8_t *>(d_in.p) + in_off[i];
-    if (len[i] && !hip_ok(hipMemcpy(dst, data[i], len[i], hipMemcpyHostToDevice), "upload stream")) return VP8L_ERR_HIP;
-    d_data[i] = dst;
-    d_argb[i] = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_out.p) + out_off[i]);
-  }
-  // images that already failed keep their status: give the device call only the valid ones
-  std::vector<const uint8_t *> v_data;
-  std::vector<size_t> v_len, v_idx;
-  std::vector<uint32_t> v_w, v_h;
-  std::vector<uint32_t *> v_out;
-  for (size_t i = 0; i < n; i++)
-    if (valid[i]) { v_idx.push_back(i); v_data.push_back(d_data[i]); v_len.push_back(len[i]); v_w.push_back(width[i]); v_h.push_back(height[i]); v_out.push_back(d_argb[i]); }
-  std::vector<int> v_status(v_idx.size(), VP8L_OK);
-  if (!v_idx.empty()) {
-    rc = vp8l_decoder_decode_device(d, v_idx.size(), v_data.data(), v_len.data(), v_w.data(), v_h.data(), v_out.data(), v_status.data());
-    if (rc != VP8L_OK) return rc;
-  }
-  for (size_t k = 0; k < v_idx.size(); k++) {
-    const size_t i = v_idx[k];
-    status[i] = v_status[k];
-    if (status[i] != VP8L_OK) continue;
-    const size_t bytes = (size_t)width[i] * height[i] * 4;
-    argb[i] = static_cast<uint32_t *>(malloc(bytes));
-    if (!argb[i]) { status[i] = VP8L_ERR_NO_MEMORY; continue; }
-    if (!hip_ok(hipMemcpy(argb[i], d_argb[i], bytes, hipMemcpyDeviceToHost), "download image")) {
-      free(argb[i]);
-      argb[i] = nullptr;
-      return VP8L_ERR_HIP;
+  if (idx.empty()) return VP8L_OK;
+  const std::vector<size_t> first = make_chunks(bytes, kDecodeChunkStreams, g_chunk_bytes, kDecodeChunkMaxBytes);
+  for (int l = 0; l < g_lanes && l < (int)first.size() - 1; l++)
+    if ((rc = lane_ready(p, p->lanes[l], false, 0)) != VP8L_OK) return rc;
+  auto work = [&](Lane &lane, size_t c) -> int {
+    const size_t k0 = first[c], m = first[c + 1] - k0;
+    std::vector<size_t> in_off(m, 0), out_off(m, 0), v_len(m, 0);
+    std::vector<uint32_t> v_w(m), v_h(m);
+    size_t in_total = 0, out_total = 0;
+    for (size_t k = 0; k < m; k++) {
+      const size_t i = idx[k0 + k];
+      in_off[k] = in_total;
+      in_total += (len[i] + 255 + 8) & ~(size_t)255;
+      out_off[k] = out_total;
+      out_total += (bytes[k0 + k] + 255) & ~(size_t)255;
+      v_len[k] = len[i];
+      v_w[k] = width[i];
+      v_h[k] = height[i];
     }
+    if (!lane.d_in.reserve(in_total + 256) || !lane.d_out.reserve(out_total + 256)) return VP8L_ERR_NO_MEMORY;
+    std::vector<const uint8_t *> d_data(m, nullptr);
+    std::vector<uint32_t *> d_argb(m, nullptr);
+    for (size_t k = 0; k < m; k++) {
+      const size_t i = idx[k0 + k];
+      uint8_t *dst = lane.d_in.as<uint8_t>() + in_off[k];
+      if (len[i] && !hip_ok(hipMemcpyAsync(dst, data[i], len[i], hipMemcpyHostToDevice, lane.copy), "upload stream")) return VP8L_ERR_HIP;
+      d_data[k] = dst;
+      d_argb[k] = reinterpret_cast<uint32_t *>(lane.d_out.as<uint8_t>() + out_off[k]);
+    }
+    if (!hip_ok(hipStreamSynchronize(lane.copy), "upload streams")) return VP8L_ERR_HIP;
+    std::vector<int> v_status(m, VP8L_OK);
+    const int r = vp8l_decoder_decode_device(lane.dec, m, d_data.data(), v_len.data(), v_w.data(), v_h.data(), d_argb.data(), v_status.data());
+    if (r != VP8L_OK) return r;
+    for (size_t k = 0; k < m; k++) {
+      const size_t i = idx[k0 + k];
+      status[i] = v_status[k];
+      if (status[i] != VP8L_OK) continue;
+      argb[i] = static_cast<uint32_t *>(malloc(bytes[k0 + k]));
+      if (!argb[i]) { status[i] = VP8L_ERR_NO_MEMORY; continue; }
+      if (!hip_ok(hipMemcpyAsync(argb[i], d_argb[k], bytes[k0 + k], hipMemcpyDeviceToHost, lane.copy), "download image")) return VP8L_ERR_HIP;
+    }
+    if (!hip_ok(hipStreamSynchronize(lane.copy), "download images")) return VP8L_ERR_HIP;
+    return VP8L_OK;
+  };
+  rc = run_chunks(p, first.size() - 1, work);
+  if (rc != VP8L_OK) {
+    for (size_t i = 0; i < n; i++) { free(argb[i]); argb[i] = nullptr; }
   }
-  return VP8L_OK;
+  return rc;
 }
 
 extern "C" int vp8l_decode(const uint8_t *data, size_t len, uint32_t **argb, uint32_t *width, uint32_t *height) {
