@@ -347,8 +347,8 @@ __global__ __launch_bounds__(64) void k_decode_entropy(const DecImage *__restric
 //      next[t] = t + bits of the token at t (a sink when the token leaves the span or is one of the
 //      rare things decoded below).
 //   2. the tokens that really start in the span are the chain 0, next[0], next[next[0]], ...  It is
-//      found without a serial walk: jump tables next^(2^k) by pointer doubling (k < 7), then marks
-//      spread from offset 0 with the widest jump first, so 128 tokens are marked in 7 steps.
+//      found without a serial walk: jump tables next^(4^k) by pointer jumping (k < 4), then marks
+//      spread from offset 0 with the widest jump first, so 128 tokens are marked in 4 steps.
 //   3. a scan of the marked tokens' pixel counts gives every token its output position.  Literals go
 //      straight into the LDS ring.  Every pixel of the round gets the position its value comes from:
 //      itself (literal), an older pixel, or a pixel of this round that a reference makes; the last kind
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64) void k_decode_entropy(const DecImage *__restric
 constexpr uint32_t kWgThreads = 1024;
 constexpr uint32_t kWgWaves = kWgThreads / 64;
 constexpr uint32_t kWgSpan = kWgThreads;      // bit offsets looked at per round, one per thread
-constexpr uint32_t kWgLevels = 7;             // jump tables next^(2^k), k < 7: at most 128 tokens per round
+constexpr uint32_t kWgLevels = 4;             // jump tables next^(4^k), k < 4: at most 2 * 64 = 128 tokens per round
 constexpr uint32_t kWgRing = 4096;            // pixels kept in LDS
 constexpr uint32_t kWgNear = 2048;            // pixels a round may produce = how far back the ring is read
 constexpr uint32_t kWgWindow = 4096;          // stream bytes kept in LDS
@@ -377,7 +377,6 @@ constexpr uint32_t kWgLongBatch = 6;          // lengths compared at once
 constexpr uint32_t kWgLongSlots = 24;         // kWgLongLens rounded up to whole batches
 constexpr uint32_t kWgJumpSteps = 12;         // source chains are at most 2048 long: 11 halvings
 static_assert(kWgSpan + 128 <= kWgWindow * 8 / 2, "a span fits the window with room to move");
-static_assert((1u << kWgLevels) <= kWgSpan, "levels");
 static_assert(kWgLongSlots % kWgLongBatch == 0 && kWgLongSlots >= kWgLongLens, "long-code slots");
 
 struct WgShared {
@@ -515,26 +514,39 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, const VP8L
       const uint64_t w = sft ? (x >> sft) | ((uint64_t)win[idx + 2] << (64 - sft)) : x;
       wg_token(w, g, sh, xsize, hop, cnt, val, ref);
     }
-    uint32_t j[kWgLevels];
-    j[0] = hop && tid + hop < kWgSpan ? tid + hop : kWgSpan;
-    sh.ja[tid] = (uint16_t)j[0];
+    // ---- 2. jump tables next^(4^k) for k < 4, then the marks
+    // Every step costs an LDS round trip and a barrier whatever it does, so a step quadruples the jump:
+    // s1/s2/s3[k] are 1, 2 and 3 jumps of 4^k tokens from this offset, the fourth is the next table's entry.
+    uint32_t s1[kWgLevels], s2[kWgLevels], s3[kWgLevels];
+    s1[0] = hop && tid + hop < kWgSpan ? tid + hop : kWgSpan;
+    sh.ja[tid] = (uint16_t)s1[0];
     sh.mark[tid] = tid == 0 ? (uint8_t)(kWgLevels + 1) : (uint8_t)0;
-    // ---- 2. jump tables, then the marks
     VP8L_LDS uint16_t *cur = sh.ja, *oth = sh.jb;
 #pragma unroll
-    for (uint32_t k = 1; k < kWgLevels; k++) {
+    for (uint32_t k = 0; k < kWgLevels; k++) {
       __syncthreads();
-      j[k] = cur[j[k - 1]];
-      oth[tid] = (uint16_t)j[k];
-      VP8L_LDS uint16_t *t16 = cur; cur = oth; oth = t16;
+      s2[k] = cur[s1[k]];
+      s3[k] = cur[s2[k]];
+      if (k + 1 < kWgLevels) {
+        s1[k + 1] = cur[s3[k]];
+        oth[tid] = (uint16_t)s1[k + 1];
+        VP8L_LDS uint16_t *t16 = cur; cur = oth; oth = t16;
+      }
     }
-    uint32_t beyond = kWgSpan;  // thread 0: where the 129th token starts, if the chain is that long
+    // chain positions 0..127 = i3 * 64 + i2 * 16 + i1 * 4 + i0 with i3 < 2 and the others < 4: offset 0 marks its
+    // 64-token jump, then every marked offset marks its three 16-token jumps, and so on down
+    const uint32_t beyond = s2[kWgLevels - 1];  // thread 0: where the 129th token starts, if the chain is that long
 #pragma unroll
     for (int k = (int)kWgLevels - 1; k >= 0; k--) {
-      __syncthreads();
-      if (k == (int)kWgLevels - 1 && tid == 0) beyond = cur[cur[0]];
+      if (k != (int)kWgLevels - 1) __syncthreads();  // the last table step ended with no write: its barrier is this step's
       // only marks older than this step spread: a mark set during the step (value k + 1) does not
-      if (sh.mark[tid] > (uint32_t)k + 1) sh.mark[j[k]] = (uint8_t)(k + 1);
+      if (sh.mark[tid] > (uint32_t)k + 1) {
+        sh.mark[s1[k]] = (uint8_t)(k + 1);
+        if (k != (int)kWgLevels - 1) {
+          sh.mark[s2[k]] = (uint8_t)(k + 1);
+          sh.mark[s3[k]] = (uint8_t)(k + 1);
+        }
+      }
     }
     __syncthreads();
     const bool on = sh.mark[tid] != 0;
@@ -560,7 +572,7 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, const VP8L
         sh.end_off = tid;  // the chain ends at something this round cannot decode
         sh.end_px = ex;
       } else {
-        if (j[0] == kWgSpan) { sh.end_off = tid + hop; sh.end_px = ex + cnt; }
+        if (s1[0] == kWgSpan) { sh.end_off = tid + hop; sh.end_px = ex + cnt; }
         if (ex + cnt > room) {
           if (ex <= room) {  // the first token that does not fit: the next round starts with it
             sh.defer_off = tid;
