@@ -1,0 +1,63 @@
+"""The host-memory batch entry points with many small chunks and few lanes (set through the environment,
+which the library reads when it is loaded: hence a child process): results must equal the oracle's image by
+image, invalid images and damaged streams keep their own status wherever they fall in a chunk."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = textwrap.dedent("""
+    import sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    sys.path.insert(0, %r)
+    import _oracle as O
+    import webp_amd
+
+    rng = np.random.default_rng(4)
+    imgs = []
+    for k in range(60):
+        if k %% 11 == 5:
+            imgs.append((np.zeros(0, np.uint32), 0, 7))            # invalid: reported, the others unaffected
+        elif k %% 13 == 7:
+            imgs.append((np.zeros(4, np.uint32), 16385, 1))        # too big
+        else:
+            w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+            imgs.append((O.gen_image((3, 4, 5)[k %% 3], w, h, 100 + k, 40), w, h))
+    res = webp_amd.encode_batch(imgs)
+    streams = []
+    for (img, w, h), (st, data) in zip(imgs, res):
+        rc, ref = O.encode(img, w, h)
+        assert st == rc, (st, rc, w, h)
+        if rc == 0:
+            assert data == ref, (w, h)
+            streams.append((data, img, w, h))
+    assert len(streams) > 40
+    # decode: damage every seventh stream
+    inputs = []
+    for k, (data, img, w, h) in enumerate(streams):
+        inputs.append(data[: len(data) // 2] if k %% 7 == 3 else data)
+    inputs.insert(5, b"")
+    inputs.insert(9, b"\\0\\0\\0\\0\\x2e\\0\\0\\0\\0")
+    out = webp_amd.decode_batch(inputs)
+    for s, (st, arr, w, h) in zip(inputs, out):
+        rc0, ref, w0, h0 = O.decode(s)
+        assert st == rc0, (st, rc0, len(s))
+        if rc0 == 0:
+            assert (w, h) == (w0, h0) and np.array_equal(arr, ref)
+    print("pipeline ok", len(streams))
+""")
+
+
+def test_many_chunks_few_lanes():
+    env = dict(os.environ, VP8L_HOST_LANES="3", VP8L_HOST_CHUNK_MB="1", VP8L_HOST_DECODE_STREAMS="5")
+    code = CHILD % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "pipeline ok" in r.stdout

@@ -60,7 +60,8 @@ namespace {
 // one chunk, the kernels of another and the download of a third overlap (copy engines and CUs work side by
 // side).  Staging buffers are kept between calls (grow-only): hipMalloc / hipFree synchronise the device.
 // Measured on a 128 x 3840x2160 batch from page-locked memory: 3 lanes x 128 MiB move 22 GB/s, 8 x 64 MiB 35 GB/s,
-// 12 x 64 MiB 39 GB/s (the link does 57 GB/s one way); VP8L_HOST_LANES / VP8L_HOST_CHUNK_MB override the defaults.
+// 12 x 64 MiB 39 GB/s (the link does 57 GB/s one way); VP8L_HOST_LANES / VP8L_HOST_CHUNK_MB /
+// VP8L_HOST_DECODE_STREAMS override the defaults.
 constexpr int kLanes = 16;  // at most
 int env_int(const char *name, int fallback, int lo, int hi) {
   const char *v = getenv(name);
@@ -72,7 +73,7 @@ const int g_lanes = env_int("VP8L_HOST_LANES", 8, 1, kLanes);
 const size_t g_chunk_bytes = (size_t)env_int("VP8L_HOST_CHUNK_MB", 64, 1, 4096) << 20;  // pixel bytes per encode chunk (at least one image)
 // The decoder runs one workgroup per stream and a stream takes as long as it takes: a chunk should hold enough
 // streams to fill the device, so chunks close at 256 streams (and at least the encode chunk size), or at 8 GiB of pixels.
-constexpr size_t kDecodeChunkStreams = 256;
+const size_t g_decode_chunk_streams = (size_t)env_int("VP8L_HOST_DECODE_STREAMS", 256, 1, 1 << 20);
 constexpr size_t kDecodeChunkMaxBytes = (size_t)8 << 30;
 
 struct Lane {
@@ -327,7 +328,7 @@ extern "C" int vp8l_decode_batch(int device, size_t n, const uint8_t *const *dat
     bytes.push_back((size_t)width[i] * height[i] * 4);
   }
   if (idx.empty()) return VP8L_OK;
-  const std::vector<size_t> first = make_chunks(bytes, kDecodeChunkStreams, g_chunk_bytes, kDecodeChunkMaxBytes);
+  const std::vector<size_t> first = make_chunks(bytes, g_decode_chunk_streams, g_chunk_bytes, kDecodeChunkMaxBytes);
   for (int l = 0; l < g_lanes && l < (int)first.size() - 1; l++)
     if ((rc = lane_ready(p, p->lanes[l], false, 0)) != VP8L_OK) return rc;
   auto work = [&](Lane &lane, size_t c) -> int {
