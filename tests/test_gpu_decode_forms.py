@@ -11,10 +11,11 @@ import webp_amd
 pytestmark = pytest.mark.gpu
 
 
-def decode_with(threads, streams):
+def decode_with(threads, streams, whole_device=1, used=None):
     """Decodes through the device-memory entry point with the given form; returns [(status, pixels)]."""
     dec = webp_amd.Decoder()
     dec.set_threads_per_stream(threads)
+    dec.set_whole_device(whole_device)
     infos = [webp_amd.get_info(s) for s in streams]
     d_streams = []
     for s in streams:
@@ -24,6 +25,8 @@ def decode_with(threads, streams):
     st = dec.decode_device([d.data_ptr() for d in d_streams], [len(s) for s in streams], [w for w, _ in infos],
                            [h for _, h in infos], [d.data_ptr() for d in d_out])
     torch.cuda.synchronize()
+    if used is not None:
+        used.append(dec.last_whole_device_streams())
     return [(int(st[i]), d_out[i].cpu().numpy().view(np.uint32)) for i in range(len(streams))]
 
 
@@ -201,3 +204,61 @@ def test_both_forms_agree_on_encoder_streams():
         assert sa == 0 and sb == 0, (k, sa, sb)
         assert np.array_equal(pa, img), k
         assert np.array_equal(pb, img), k
+
+
+def test_whole_device_form():
+    """Large streams cut into segments and decoded by many workgroups: same pixels and verdicts."""
+    cases = [(3, 1100, 700), (4, 1100, 700), (5, 1024, 600), (4, 4096, 40), (3, 300, 300), (3, 40, 40), (4, 2000, 1100)]
+    imgs = [O.gen_image(m, w, h, 700 + w, 200) for m, w, h in cases]
+    flat = np.full(700 * 500, 0xFF336699, dtype=np.uint32)
+    flat[::7919] ^= 0x010101
+    imgs.append(flat)
+    cases.append((0, 700, 500))
+    streams = []
+    for img, (m, w, h) in zip(imgs, cases):
+        rc, s = O.encode(img, w, h)
+        assert rc == 0
+        streams.append(s)
+    # the main image behind a predictor transform, and two kinds the segment kernels leave to one workgroup
+    for prm in (dict(predictor_bits=4, use_subtract_green=1), dict(cache_bits=5), dict(meta_bits=3, meta_groups=3)):
+        rc, s = O.encode_ext(imgs[0], 1100, 700, **prm)
+        assert rc == 0
+        streams.append(s)
+        imgs.append(imgs[0])
+    used = []
+    res = decode_with(1024, streams, whole_device=2, used=used)
+    for k, ((st, px), img) in enumerate(zip(res, imgs)):
+        assert st == 0, (k, st)
+        assert np.array_equal(px, img), k
+    assert used[0] >= 7, used  # the large one-group streams went through the segment kernels
+    # damaged streams: the verdict and the pixels of the one-workgroup form
+    rng = np.random.default_rng(12)
+    bad = []
+    for base in (streams[0], streams[1], streams[6]):
+        for it in range(12):
+            b = bytearray(base)
+            if it % 3 == 0:
+                b = b[: int(rng.integers(len(b) // 2, len(b)))]
+            else:
+                pos = int(rng.integers(len(b) // 4, len(b)))
+                b[pos] ^= 1 << int(rng.integers(0, 8))
+            bad.append(bytes(b))
+    a = decode_with(1024, bad, whole_device=2)
+    b = decode_with(1024, bad, whole_device=1)
+    for k, ((sa, pa), (sb, pb)) in enumerate(zip(a, b)):
+        assert sa == sb, (k, sa, sb)
+        if sa == 0:
+            assert np.array_equal(pa, pb), k
+
+
+def test_whole_device_handmade_tokens():
+    streams, expect = [], []
+    for w, h, toks in handmade_cases():
+        s, e = handmade_stream(w, h, toks)
+        rc0, ref, w0, h0 = O.decode(s)
+        streams.append(s)
+        expect.append((rc0, ref))
+    for (st, px), (rc0, ref) in zip(decode_with(1024, streams, whole_device=2), expect):
+        assert st == rc0, (st, rc0)
+        if rc0 == 0:
+            assert np.array_equal(px, ref)

@@ -36,9 +36,11 @@ dec = webp_amd.Decoder()
 for a in sys.argv:
     if a.startswith("--dec-threads="):
         dec.set_threads_per_stream(int(a.split("=")[1]))
+    if a.startswith("--whole-device="):
+        dec.set_whole_device(int(a.split("=")[1]))
 d_dec = torch.empty((batch, w * h), dtype=torch.int32, device="cuda")
 args = ([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], [w] * batch, [h] * batch, [d_dec[k].data_ptr() for k in range(batch)])
 for it in range(2):
     stt = dec.decode_device(*args)
 assert (stt == 0).all() and torch.equal(d_dec, d_in)
-print("  decode: %.1f MP/s (device time %.1f ms)" % (mp / dec.last_device_seconds(), 1e3 * dec.last_device_seconds()))
+print("  decode: %.1f MP/s (device time %.1f ms, %d streams by the whole device)" % (mp / dec.last_device_seconds(), 1e3 * dec.last_device_seconds(), dec.last_whole_device_streams()))

@@ -29,6 +29,7 @@ STATUS_NAMES = {
 }
 STAGE_RESIDUAL, STAGE_MATCH, STAGE_HISTO, STAGE_CODELEN, STAGE_INFO, STAGE_PRED_MODES = range(6)
 DEC_OPT_THREADS_PER_STREAM = 1
+DEC_OPT_WHOLE_DEVICE = 2
 ENCODE_STAGES = ("palette", "transform", "match", "parse", "histogram", "header", "bitcount_scan", "emit",
                  "match_fallback")  # the last one is the part of "match" spent in the exhaustive kernel
 
@@ -92,6 +93,8 @@ def lib():
         L.vp8l_decoder_last_device_seconds.argtypes = [C.c_void_p]
         L.vp8l_decoder_last_device_seconds.restype = C.c_double
         L.vp8l_decoder_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.vp8l_decoder_last_whole_device_streams.argtypes = [C.c_void_p]
+        L.vp8l_decoder_last_whole_device_streams.restype = C.c_long
         L.vp8l_generate_device.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         _lib = L
     return _lib
@@ -104,6 +107,7 @@ EXPORTED_SYMBOLS = (
     "vp8l_decoder_decode_device", "vp8l_encoder_last_device_seconds", "vp8l_encoder_last_stage_seconds",
     "vp8l_decoder_last_device_seconds", "vp8l_generate_device", "vp8l_encoder_set_option",
     "vp8l_encoder_last_dense_tiles", "vp8l_decoder_set_option",
+    "vp8l_decoder_last_whole_device_streams",
 )
 
 
@@ -325,6 +329,15 @@ class Decoder:
 
     def last_device_seconds(self):
         return lib().vp8l_decoder_last_device_seconds(self._h)
+
+    def set_whole_device(self, mode):
+        """0 = chosen per call, 1 = never, 2 = always: large streams decoded by many workgroups (same pixels)."""
+        rc = lib().vp8l_decoder_set_option(self._h, DEC_OPT_WHOLE_DEVICE, int(mode))
+        if rc != OK:
+            raise Vp8lError(rc, "vp8l_decoder_set_option")
+
+    def last_whole_device_streams(self):
+        return int(lib().vp8l_decoder_last_whole_device_streams(self._h))
 
     def set_threads_per_stream(self, threads):
         """0 or 1024 = a workgroup per stream (default), 64 = a wave per stream (same pixels either way)."""

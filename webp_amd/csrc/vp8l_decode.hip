@@ -32,6 +32,7 @@ struct DecImage {  // host-written
   uint16_t *sorted;       // (group_cap + 1) * kSortedPerGroup: symbols in code order, read for codes longer than the lookup table
   uint32_t group_cap;
   uint32_t pad;
+  struct ParImage *par;   // workspace of the segment kernels (one large stream decoded by the whole device), or null
 };
 
 struct DecResult {  // device-written
@@ -396,9 +397,10 @@ struct WgShared {
   uint16_t sorted[kWgSorted];                 // symbols in code order
 };
 
-__device__ __forceinline__ void wg_window_load(VP8L_LDS uint32_t *win, const DecImage &im, uint64_t lo, uint32_t tid) {
+__device__ __forceinline__ void wg_window_load(VP8L_LDS uint32_t *win, const DecImage &im, uint64_t lo, uint32_t tid,
+                                               uint32_t words = kWgWindowWords) {
   const uint32_t *src = reinterpret_cast<const uint32_t *>(im.data);  // 4-byte aligned; bytes past the end read as zero
-  for (uint32_t i = tid; i < kWgWindowWords; i += kWgThreads) {
+  for (uint32_t i = tid; i < words; i += kWgThreads) {
     const uint64_t pos = lo + 4ull * i;
     uint32_t v = 0;
     if (pos + 4 <= im.len) v = src[pos >> 2];
@@ -430,6 +432,22 @@ __device__ __forceinline__ bool wg_sym(uint64_t w, uint32_t &n, const VP8L_LDS H
   sym = sh.sorted[sh.base[code][slot] + (v >> (32 - l))];
   n += l;
   return true;
+}
+
+// What wg_sym needs for codes longer than the lookup table (a barrier must follow before the first use).
+__device__ __forceinline__ void wg_prepare_long(VP8L_LDS WgShared &sh, const VP8L_LDS GroupTables &g, uint32_t tid) {
+  for (uint32_t i = tid; i < kWgSorted; i += kWgThreads) sh.sorted[i] = g.sorted[i];
+  if (tid < kNumCodes * kWgLongSlots) {
+    const uint32_t c = tid / kWgLongSlots, slot = tid % kWgLongSlots, l = kLutBits + 1 + slot;
+    const VP8L_LDS HuffTable &t = g.t[c];
+    uint32_t lim = 0xffffffffu, base = 0;
+    if (l <= t.maxlen) {
+      lim = (uint32_t)(((uint64_t)(t.first[l] + t.count[l]) << (32 - l)) - 1ull);  // not zero: some code is at most 9 bits long
+      base = t.sorted_off + t.index[l] - t.first[l];
+    }
+    sh.lim[c][slot] = lim;
+    sh.base[c][slot] = base;
+  }
 }
 
 // The token that starts at bit 0 of w: hop = its bits (0: not decodable from w alone), cnt = pixels it
@@ -475,18 +493,7 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, const VP8L
   uint64_t P = st.bytepos * 8 - st.cnt;  // position in the stream, in bits
   const uint32_t total = (uint32_t)st.total, xsize = st.xsize;
   uint32_t *dst = st.dst;
-  for (uint32_t i = tid; i < kWgSorted; i += kWgThreads) sh.sorted[i] = g.sorted[i];
-  if (tid < kNumCodes * kWgLongSlots) {
-    const uint32_t c = tid / kWgLongSlots, slot = tid % kWgLongSlots, l = kLutBits + 1 + slot;
-    const VP8L_LDS HuffTable &t = g.t[c];
-    uint32_t lim = 0xffffffffu, base = 0;
-    if (l <= t.maxlen) {
-      lim = (uint32_t)(((uint64_t)(t.first[l] + t.count[l]) << (32 - l)) - 1ull);  // not zero: some code is at most 9 bits long
-      base = t.sorted_off + t.index[l] - t.first[l];
-    }
-    sh.lim[c][slot] = lim;
-    sh.base[c][slot] = base;
-  }
+  wg_prepare_long(sh, g, tid);
   uint32_t fill = 0, flushed = 0;  // flushed: multiple of 64, everything before it is in HBM
   uint64_t win_bit0 = 0;
   bool have_window = false;
@@ -758,6 +765,351 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, const VP8L
   }
 }
 
+
+// =============================================================================================
+// One large stream decoded by the whole device.
+// A workgroup decodes a stream at the rate of one CU.  For a few large streams the main image is cut
+// into segments of 64 spans (65536 stream bits) that are decoded by as many workgroups:
+//   k_par_maps    per segment and for each of the 64 bit offsets at which the token chain can enter it (a
+//                 token is at most 64 bits long): where the chain leaves the segment and how many pixels it
+//                 makes on the way.  Per span this is pointer jumping over (next offset, exit, pixels) for all
+//                 1024 offsets, then the spans' maps are composed; no pixel is produced.
+//   k_par_chain   per stream, serially over its segments: the entry offset and the first pixel of every
+//                 segment (one table lookup per segment).
+//   k_par_pixels  per segment again, now knowing where to start: tokens -> literals into the image, and for
+//                 every pixel a reference makes the position its value comes from.
+//   k_par_jump    pointer jumping over all pixels until every pixel points at a literal (log2 of the longest
+//                 chain of references passes); k_par_gather fetches the values.
+// A token the span decoder cannot take (longer than 64 bits, zero bits, a reference longer than 255), or a
+// stream that ends early, sends the stream back to the one-workgroup form (status kParFallback).
+// =============================================================================================
+constexpr uint32_t kParSpans = 64;
+constexpr uint32_t kParSegBits = kParSpans * kWgSpan;
+constexpr uint32_t kParWindowWords = kParSegBits / 32 + 16;
+constexpr uint32_t kParStop = 0x7f, kParNone = 0xff;   // exit codes next to the bit offsets 0..63
+constexpr uint32_t kParMinPixels = 1u << 16;            // smaller images are not worth the extra passes
+constexpr uint32_t kParJumpPasses = 32;
+constexpr int32_t kParPending = 1, kParFallback = 2;    // DecResult.status values that are not verdicts
+constexpr uint32_t kFinalBit = 0x80000000u;             // in the per-pixel source array: this position holds its final value
+
+struct ParImage {
+  // set by the host
+  uint32_t *srcg;      // per pixel: position its value comes from (| kFinalBit)
+  uint64_t *segmap;    // nseg * 64: exit | pixels << 32 for each entry offset
+  uint32_t *segentry;  // nseg + 1: bit offset at which the chain enters the segment
+  uint32_t *segbase;   // nseg + 1: first pixel of the segment (>= total: nothing left for it)
+  uint32_t nseg;
+  // set on the device
+  uint32_t active;
+  int32_t status;
+  uint32_t total, xsize;
+  uint32_t pad;
+  uint64_t P0;         // stream position of the first token, in bits
+  uint32_t *dst;
+  uint32_t changed[kParJumpPasses];
+  GroupTables tables;
+};
+
+__device__ __forceinline__ void par_fail(ParImage *par, int32_t code) {
+  // a fallback wins over a verdict (the one-workgroup form then gives the verdict); among verdicts the first stays
+  if (code == kParFallback) atomicExch(&par->status, code);
+  else atomicCAS(&par->status, (int32_t)kOk, code);
+}
+
+// Tables and long-code lists into LDS, the segment's stream bytes into the window.  Returns the window's first bit.
+__device__ __forceinline__ uint64_t par_setup(VP8L_LDS GroupTables &g, VP8L_LDS WgShared &sh, VP8L_LDS uint32_t *win, const DecImage &im,
+                                              const ParImage *par, uint32_t seg, uint32_t tid) {
+  for (uint32_t i = tid; i < sizeof(GroupTables) / 4; i += kWgThreads)
+    reinterpret_cast<VP8L_LDS uint32_t *>(&g)[i] = reinterpret_cast<const uint32_t *>(&par->tables)[i];
+  const uint64_t sb = par->P0 + (uint64_t)seg * kParSegBits, lo = (sb >> 3) & ~3ull;
+  wg_window_load(win, im, lo, tid, kParWindowWords);
+  __syncthreads();
+  wg_prepare_long(sh, g, tid);
+  __syncthreads();
+  return lo * 8;
+}
+
+__device__ __forceinline__ uint64_t par_window_bits(const VP8L_LDS uint32_t *win, uint32_t a) {  // 64 stream bits from bit a of the window
+  const uint32_t idx = a >> 5, sft = a & 31u;
+  const uint64_t x = (uint64_t)win[idx] | ((uint64_t)win[idx + 1] << 32);
+  return sft ? (x >> sft) | ((uint64_t)win[idx + 2] << (64 - sft)) : x;
+}
+
+__global__ __launch_bounds__(kWgThreads) void k_par_maps(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ segfirst, uint32_t n) {
+  __shared__ GroupTables g;
+  __shared__ uint32_t win[kParWindowWords];
+  __shared__ __attribute__((aligned(16))) WgShared sh;
+  __shared__ uint64_t ea[kWgSpan + 1], eb[kWgSpan + 1];  // per offset: next offset | exit << 16 | pixels << 32; entry kWgSpan is the sink
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t img = find_image(segfirst, n, blockIdx.x), seg = blockIdx.x - segfirst[img];
+  const DecImage im = imgs[img];
+  ParImage *par = im.par;
+  if (!par || !par->active || seg >= par->nseg) return;
+  const uint64_t bit0 = par_setup((VP8L_LDS GroupTables &)g, (VP8L_LDS WgShared &)sh, (VP8L_LDS uint32_t *)win, im, par, seg, tid);
+  const uint32_t first = (uint32_t)(par->P0 + (uint64_t)seg * kParSegBits - bit0), xsize = par->xsize;
+  const uint64_t sink = (uint64_t)kWgSpan | ((uint64_t)kParNone << 16);
+  if (tid == 0) { ea[kWgSpan] = sink; eb[kWgSpan] = sink; }
+  uint32_t at = lane, made = 0;  // wave 0, lane e: where the chain that entered the segment at offset e is now, pixels so far
+  for (uint32_t s = 0; s < kParSpans; s++) {
+    __syncthreads();
+    uint32_t hop, cnt, val;
+    bool ref;
+    wg_token(par_window_bits((VP8L_LDS uint32_t *)win, first + s * kWgSpan + tid), (const VP8L_LDS GroupTables &)g, (const VP8L_LDS WgShared &)sh, xsize,
+             hop, cnt, val, ref);
+    const uint32_t nxt = hop && tid + hop < kWgSpan ? tid + hop : kWgSpan;
+    const uint32_t ex0 = hop == 0 ? kParStop : (tid + hop >= kWgSpan ? tid + hop - kWgSpan : kParNone);
+    uint64_t pk = (uint64_t)nxt | ((uint64_t)ex0 << 16) | ((uint64_t)(hop ? cnt : 0u) << 32);
+    ea[tid] = pk;
+    VP8L_LDS uint64_t *cur = (VP8L_LDS uint64_t *)ea, *oth = (VP8L_LDS uint64_t *)eb;
+#pragma unroll
+    for (uint32_t lev = 0; lev < 5; lev++) {  // 4^5 tokens: more than a span can hold
+      __syncthreads();
+      const uint64_t e1 = cur[(uint32_t)pk & 0xffffu], e2 = cur[(uint32_t)e1 & 0xffffu], e3 = cur[(uint32_t)e2 & 0xffffu];
+      uint32_t ex = (uint32_t)(pk >> 16) & 0xffu;  // the first exit on the way
+      if (ex == kParNone) ex = (uint32_t)(e1 >> 16) & 0xffu;
+      if (ex == kParNone) ex = (uint32_t)(e2 >> 16) & 0xffu;
+      if (ex == kParNone) ex = (uint32_t)(e3 >> 16) & 0xffu;
+      const uint32_t px = (uint32_t)(pk >> 32) + (uint32_t)(e1 >> 32) + (uint32_t)(e2 >> 32) + (uint32_t)(e3 >> 32);
+      pk = (e3 & 0xffffull) | ((uint64_t)ex << 16) | ((uint64_t)px << 32);
+      if (lev < 4) {
+        oth[tid] = pk;
+        VP8L_LDS uint64_t *t = cur; cur = oth; oth = t;
+      }
+    }
+    if (wave == 0) {  // lane e now holds the span's map for entry e; move every tracked chain through it
+      const uint32_t ex = (uint32_t)(pk >> 16) & 0xffu, px = (uint32_t)(pk >> 32);
+      const uint32_t nex = (uint32_t)__shfl((int)ex, (int)(at & 63u), 64), npx = (uint32_t)__shfl((int)px, (int)(at & 63u), 64);
+      if (at != kParStop) { made += npx; at = nex; }
+    }
+  }
+  if (wave == 0) par->segmap[(size_t)seg * 64 + lane] = (uint64_t)at | ((uint64_t)made << 32);
+}
+
+__global__ __launch_bounds__(256) void k_par_chain(const DecImage *__restrict__ imgs) {
+  constexpr uint32_t kChunk = 32;
+  __shared__ uint64_t chunk[kChunk * 64];
+  const uint32_t tid = threadIdx.x;
+  ParImage *par = imgs[blockIdx.x].par;
+  if (!par || !par->active) return;
+  const uint32_t nseg = par->nseg, total = par->total;
+  uint32_t e = 0;
+  uint64_t base = 0;
+  bool stopped = false;  // thread 0
+  for (uint32_t g0 = 0; g0 < nseg; g0 += kChunk) {
+    const uint32_t cnt = nseg - g0 < kChunk ? nseg - g0 : kChunk;
+    for (uint32_t i = tid; i < cnt * 64; i += 256) chunk[i] = par->segmap[(size_t)g0 * 64 + i];
+    __syncthreads();
+    if (tid == 0) {
+      for (uint32_t k = 0; k < cnt; k++) {
+        par->segentry[g0 + k] = e;
+        par->segbase[g0 + k] = base < total && !stopped ? (uint32_t)base : total;
+        if (base >= total || stopped) continue;
+        const uint64_t m = chunk[k * 64 + e];
+        base += m >> 32;
+        const uint32_t x = (uint32_t)m & 0xffu;
+        if (x == kParStop) stopped = true;
+        else e = x;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    par->segentry[nseg] = e;
+    par->segbase[nseg] = total;
+    // the chain must reach the end of the image inside the segments, without meeting a token the span decoder cannot take
+    if (base < total) par_fail(par, kParFallback);
+  }
+}
+
+__global__ __launch_bounds__(kWgThreads) void k_par_pixels(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ segfirst, uint32_t n) {
+  __shared__ GroupTables g_;
+  __shared__ uint32_t win_[kParWindowWords];
+  __shared__ __attribute__((aligned(16))) WgShared sh_;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t img = find_image(segfirst, n, blockIdx.x), seg = blockIdx.x - segfirst[img];
+  const DecImage im = imgs[img];
+  ParImage *par = im.par;
+  if (!par || !par->active || seg >= par->nseg || par->status != kOk) return;
+  const uint32_t total = par->total, xsize = par->xsize;
+  uint32_t fill = par->segbase[seg];
+  if (fill >= total) return;
+  VP8L_LDS GroupTables &g = (VP8L_LDS GroupTables &)g_;
+  VP8L_LDS WgShared &sh = (VP8L_LDS WgShared &)sh_;
+  VP8L_LDS uint32_t *win = (VP8L_LDS uint32_t *)win_;
+  const uint64_t bit0 = par_setup(g, sh, win, im, par, seg, tid);
+  const uint32_t first = (uint32_t)(par->P0 + (uint64_t)seg * kParSegBits - bit0);
+  // window bit positions: where this segment's chain starts, and where the next segment's takes over
+  uint32_t P = first + par->segentry[seg];
+  const uint32_t hard_end = kParWindowWords * 32 - 192;  // nothing is read beyond the window
+  const uint32_t P_end = par->segbase[seg + 1] < total ? first + kParSegBits + par->segentry[seg + 1] : hard_end;
+  uint32_t *dst = par->dst, *srcg = par->srcg;
+  if (tid == 0) sh.status = kOk;
+  int32_t status = kOk;
+  while (P < P_end && fill < total) {
+    __syncthreads();
+    const uint32_t lim = P_end - P;  // offsets from here on belong to the next segment
+    uint32_t hop = 0, cnt = 0, val = 0;
+    bool ref = false;
+    if (tid < lim) wg_token(par_window_bits(win, P + tid), g, sh, xsize, hop, cnt, val, ref);
+    // ---- the chain from offset 0, as in wg_decode_pixels
+    uint32_t s1[kWgLevels], s2[kWgLevels], s3[kWgLevels];
+    s1[0] = hop && tid + hop < kWgSpan ? tid + hop : kWgSpan;
+    sh.ja[tid] = (uint16_t)s1[0];
+    sh.mark[tid] = tid == 0 ? (uint8_t)(kWgLevels + 1) : (uint8_t)0;
+    if (tid == 0) { sh.ja[kWgSpan] = (uint16_t)kWgSpan; sh.jb[kWgSpan] = (uint16_t)kWgSpan; }
+    VP8L_LDS uint16_t *cur = sh.ja, *oth = sh.jb;
+#pragma unroll
+    for (uint32_t k = 0; k < kWgLevels; k++) {
+      __syncthreads();
+      s2[k] = cur[s1[k]];
+      s3[k] = cur[s2[k]];
+      if (k + 1 < kWgLevels) {
+        s1[k + 1] = cur[s3[k]];
+        oth[tid] = (uint16_t)s1[k + 1];
+        VP8L_LDS uint16_t *t16 = cur; cur = oth; oth = t16;
+      }
+    }
+    const uint32_t beyond = s2[kWgLevels - 1];
+#pragma unroll
+    for (int k = (int)kWgLevels - 1; k >= 0; k--) {
+      if (k != (int)kWgLevels - 1) __syncthreads();
+      if (sh.mark[tid] > (uint32_t)k + 1) {
+        sh.mark[s1[k]] = (uint8_t)(k + 1);
+        if (k != (int)kWgLevels - 1) {
+          sh.mark[s2[k]] = (uint8_t)(k + 1);
+          sh.mark[s3[k]] = (uint8_t)(k + 1);
+        }
+      }
+    }
+    __syncthreads();
+    const bool on = sh.mark[tid] != 0;
+    const uint32_t c = on && hop ? cnt : 0u;
+    const uint32_t incl = wave_incl_scan_u32(c, (int)lane);
+    if (lane == 63) sh.wsum[wave] = incl;
+    if (tid == 0) { sh.defer_off = 0xffffffffu; sh.end_off = 0; sh.end_px = 0; }
+    __syncthreads();
+    const uint32_t wsums = wave_incl_scan_u32(lane < kWgWaves ? sh.wsum[lane] : 0u, (int)lane);
+    const uint32_t before = wave ? lane_read(wsums, wave - 1) : 0u, all = lane_read(wsums, kWgWaves - 1);
+    const uint32_t ex = before + incl - c, room = total - fill;
+    if (tid == 0 && beyond != kWgSpan) { sh.end_off = beyond; sh.end_px = all; }
+    bool expand = false;
+    const uint32_t pos = fill + ex;
+    if (on) {
+      if (hop == 0) {
+        sh.end_off = tid;
+        sh.end_px = ex;
+      } else {
+        if (s1[0] == kWgSpan) { sh.end_off = tid + hop; sh.end_px = ex + cnt; }
+        if (ex + cnt > room) {
+          if (ex <= room) {
+            sh.defer_off = tid;
+            sh.defer_px = ex;
+            if (ex < room) sh.status = kErrInvalidVp8l;  // a reference that runs past the end of the image
+          }
+        } else if (!ref) {
+          dst[pos] = val;
+          srcg[pos] = pos | kFinalBit;
+        } else if (val > pos) {
+          sh.status = kErrInvalidVp8l;  // a reference before the start of the image
+        } else {
+          expand = true;
+        }
+      }
+    }
+    // pixels that references make: only where their values come from, to be resolved by k_par_jump
+    if (expand && cnt <= kWgOwnCopy) {
+      if (val >= cnt) {
+        for (uint32_t e = 0; e < cnt; e++) srcg[pos + e] = pos - val + e;
+      } else {
+        for (uint32_t e = 0; e < cnt; e++) srcg[pos + e] = pos - val + e % val;
+      }
+    }
+    {
+      uint64_t m = __ballot(expand && cnt > kWgOwnCopy);
+      while (m) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t p2 = lane_read(pos, l), n2 = lane_read(cnt, l), dist = lane_read(val, l);
+        for (uint32_t c2 = 0; c2 < n2; c2 += 64) {
+          const uint32_t e = c2 + lane;
+          if (e < n2) srcg[p2 + e] = p2 - dist + (dist < n2 ? e % dist : e);
+        }
+      }
+    }
+    __syncthreads();
+    status = sh.status;
+    if (status != kOk) break;
+    const bool deferred = sh.defer_off != 0xffffffffu;
+    const uint32_t adv = deferred ? sh.defer_off : sh.end_off, produced = deferred ? sh.defer_px : sh.end_px;
+    if (adv == 0 && produced == 0) { status = kParFallback; break; }  // not expected after k_par_maps found its way through
+    fill += produced;
+    P += adv;
+  }
+  if (tid == 0) {
+    if (status != kOk) par_fail(par, status);
+    // the chain of this segment must end exactly where the next one starts
+    else if (fill < total && P != P_end) par_fail(par, kParFallback);
+  }
+}
+
+// sb_first / units as for the inverse transforms: a unit of kUnit pixels per workgroup
+__global__ __launch_bounds__(256) void k_par_jump(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t pass) {
+  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb);
+  ParImage *par = imgs[img].par;
+  if (!par || !par->active || par->status != kOk) return;
+  if (pass > 0 && !par->changed[pass - 1]) return;  // the pass before left nothing open
+  const uint64_t p0 = (uint64_t)(unit - sb_first[img] * kUnitsPerSuper) * kUnit;
+  uint32_t *srcg = par->srcg;
+  const uint32_t total = par->total;
+  bool open = false;
+  for (uint32_t k = 0; k < kUnit / 256; k++) {
+    const uint64_t p = p0 + k * 256 + threadIdx.x;
+    if (p < total) {
+      const uint32_t v = srcg[p];
+      if (!(v & kFinalBit)) {
+        // the source's own source; read while its owner replaces it, it is the old or the new one: both lead to the same literal
+        const uint32_t t = __hip_atomic_load(&srcg[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&srcg[p], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        open = open || !(t & kFinalBit);
+      }
+    }
+  }
+  if (__syncthreads_or(open) && threadIdx.x == 0) par->changed[pass] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_par_gather(const DecImage *__restrict__ imgs, DecResult *__restrict__ res, const uint32_t *__restrict__ sb_first,
+                                                    uint32_t n) {
+  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb);
+  ParImage *par = imgs[img].par;
+  if (!par || !par->active) return;
+  const uint64_t p0 = (uint64_t)(unit - sb_first[img] * kUnitsPerSuper) * kUnit;
+  // a chain of references longer than 2^32 passes cannot exist; one still open here means the passes were cut short
+  int32_t status = par->status;
+  if (status == kOk && par->changed[kParJumpPasses - 1]) status = kParFallback;
+  if (status == kOk) {
+    uint32_t *dst = par->dst;
+    const uint32_t *srcg = par->srcg;
+    const uint32_t total = par->total;
+    for (uint32_t k = 0; k < kUnit / 256; k++) {
+      const uint64_t p = p0 + k * 256 + threadIdx.x;
+      if (p < total) {
+        const uint32_t s = srcg[p] & ~kFinalBit;
+        if (s != p) dst[p] = dst[s];  // s is a literal's position: written by k_par_pixels, never by this kernel
+      }
+    }
+  }
+}
+
+// After everything else of the segment path: the verdict the inverse transforms and the host see.
+__global__ void k_par_finish(const DecImage *__restrict__ imgs, DecResult *__restrict__ res) {
+  ParImage *par = imgs[blockIdx.x].par;
+  if (!par || !par->active) return;
+  int32_t status = par->status;
+  if (status == kOk && par->changed[kParJumpPasses - 1]) status = kParFallback;
+  res[blockIdx.x].status = status;
+  res[blockIdx.x].pad = 1;  // decoded by the segment kernels
+}
+
 __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage *__restrict__ imgs, DecResult *__restrict__ res) {
   __shared__ DecState st;
   __shared__ GroupTables g0;
@@ -792,6 +1144,22 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
     const uint32_t ev = s_ev;
     if (ev == kEvDone) break;
     if (ev == kEvPixels) {
+      if (im.par && st.dst == st.out && st.total >= kParMinPixels) {
+        // the main image of a large stream: its pixels are decoded by the segment kernels that follow, from these tables
+        ParImage *par = im.par;
+        for (uint32_t i = tid; i < sizeof(GroupTables) / 4; i += kWgThreads)
+          reinterpret_cast<uint32_t *>(&par->tables)[i] = reinterpret_cast<const uint32_t *>(&g0)[i];
+        if (tid == 0) {
+          par->P0 = st.bytepos * 8 - st.cnt;
+          par->total = (uint32_t)st.total;
+          par->xsize = st.xsize;
+          par->dst = st.dst;
+          par->active = 1;
+          st.status = kParPending;
+        }
+        __syncthreads();
+        break;
+      }
       wg_decode_pixels((VP8L_LDS DecState *)&st, (const VP8L_LDS GroupTables *)&g0, (VP8L_LDS uint32_t *)ros.ring,
                        (VP8L_LDS uint32_t *)win, (VP8L_LDS WgShared *)&sh, im, tid);
     } else if (ev == kEvRefill) {
@@ -948,8 +1316,11 @@ struct vp8l_decoder {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
   DeviceBuffer d_imgs, d_res, d_sbfirst, d_aux, d_scratch, d_groups, d_cache, d_sorted;
+  DeviceBuffer d_par, d_srcg, d_segmap, d_segidx, d_segfirst;  // the segment kernels' workspace
   double last_seconds = 0;
   int threads_per_stream = 0;  // 0: chosen per call
+  int whole_device = 0;        // 0: chosen per call, 1: never, 2: whenever the stream qualifies
+  uint32_t last_whole_device = 0;  // streams of the last call that the segment kernels decoded
 };
 
 extern "C" int vp8l_decoder_set_option(vp8l_decoder *d, int option, int value) {
@@ -957,6 +1328,10 @@ extern "C" int vp8l_decoder_set_option(vp8l_decoder *d, int option, int value) {
   std::lock_guard<std::mutex> lock(d->mu);
   if (option == VP8L_DEC_OPT_THREADS_PER_STREAM && (value == 0 || value == 64 || value == (int)kWgThreads)) {
     d->threads_per_stream = value;
+    return VP8L_OK;
+  }
+  if (option == VP8L_DEC_OPT_WHOLE_DEVICE && value >= 0 && value <= 2) {
+    d->whole_device = value;
     return VP8L_OK;
   }
   return VP8L_ERR_BAD_ARGUMENT;
@@ -984,7 +1359,8 @@ extern "C" void vp8l_decoder_destroy(vp8l_decoder *d) {
   if (d->stream) (void)hipStreamSynchronize(d->stream);
   if (d->ev0) (void)hipEventDestroy(d->ev0);
   if (d->ev1) (void)hipEventDestroy(d->ev1);
-  DeviceBuffer *bufs[] = {&d->d_imgs, &d->d_res, &d->d_sbfirst, &d->d_aux, &d->d_scratch, &d->d_groups, &d->d_cache, &d->d_sorted};
+  DeviceBuffer *bufs[] = {&d->d_imgs, &d->d_res, &d->d_sbfirst, &d->d_aux, &d->d_scratch, &d->d_groups, &d->d_cache, &d->d_sorted,
+                          &d->d_par, &d->d_srcg, &d->d_segmap, &d->d_segidx, &d->d_segfirst};
   for (auto *b : bufs) b->release();
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
@@ -994,12 +1370,13 @@ namespace {
 
 // One pass over the images listed in `idx` with `group_cap` multi-group table sets per image.
 int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t *const *d_data, const size_t *len,
-                const uint32_t *width, const uint32_t *height, uint32_t *const *d_argb, uint32_t group_cap,
+                const uint32_t *width, const uint32_t *height, uint32_t *const *d_argb, uint32_t group_cap, bool whole_device,
                 std::vector<DecResult> &results) {
   const uint32_t m = (uint32_t)idx.size();
   std::vector<DecImage> imgs(m);
-  std::vector<uint32_t> sb_first(m + 1, 0);
-  uint64_t aux_total = 0, scratch_total = 0, sb_total = 0;
+  std::vector<uint32_t> sb_first(m + 1, 0), seg_first(m + 1, 0);
+  std::vector<ParImage> pars(whole_device ? m : 0);
+  uint64_t aux_total = 0, scratch_total = 0, sb_total = 0, px_total = 0, seg_total = 0;
   for (uint32_t k = 0; k < m; k++) {
     const uint32_t i = idx[k], w = width[i], h = height[i];
     DecImage &im = imgs[k];
@@ -1017,8 +1394,23 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
     sb_first[k] = (uint32_t)sb_total;
     sb_total += ((uint64_t)w * h + kSuper - 1) / kSuper;
     if (sb_total > 0x3fffffffu) return VP8L_ERR_NO_MEMORY;
+    im.par = nullptr;
+    if (whole_device) {
+      // segments that can hold tokens: the stream's bits, and one more for the bits read as zero past its end
+      const uint64_t nseg = ((uint64_t)len[i] * 8 + kParSegBits - 1) / kParSegBits + 1;
+      memset(&pars[k], 0, sizeof(ParImage));
+      pars[k].nseg = (uint32_t)nseg;
+      pars[k].srcg = reinterpret_cast<uint32_t *>(px_total);  // offsets for now
+      pars[k].segmap = reinterpret_cast<uint64_t *>(seg_total * 64);
+      pars[k].segentry = reinterpret_cast<uint32_t *>((seg_total + k) * 2);
+      seg_first[k] = (uint32_t)seg_total;
+      px_total += ((uint64_t)w * h + 63) & ~63ull;
+      seg_total += nseg;
+      if (seg_total > 0x3fffffffu) return VP8L_ERR_NO_MEMORY;
+    }
   }
   sb_first[m] = (uint32_t)sb_total;
+  seg_first[m] = (uint32_t)seg_total;
   const bool ok = d->d_imgs.reserve(m * sizeof(DecImage)) && d->d_res.reserve(m * sizeof(DecResult)) &&
                   d->d_sbfirst.reserve((m + 1) * 4) && d->d_aux.reserve(aux_total * 4) &&
                   d->d_scratch.reserve(scratch_total * 4) &&
@@ -1026,6 +1418,18 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
                   d->d_cache.reserve((size_t)m * (4u << kMaxCacheBits)) &&
                   d->d_sorted.reserve((size_t)m * (group_cap + 1) * kSortedPerGroup * 2);
   if (!ok) return VP8L_ERR_NO_MEMORY;
+  if (whole_device) {
+    if (!d->d_par.reserve(m * sizeof(ParImage)) || !d->d_srcg.reserve(px_total * 4) || !d->d_segmap.reserve(seg_total * 64 * 8) ||
+        !d->d_segidx.reserve((seg_total + m) * 2 * 4) || !d->d_segfirst.reserve((m + 1) * 4))
+      return VP8L_ERR_NO_MEMORY;
+    for (uint32_t k = 0; k < m; k++) {
+      pars[k].srcg = d->d_srcg.as<uint32_t>() + reinterpret_cast<uintptr_t>(pars[k].srcg);
+      pars[k].segmap = d->d_segmap.as<uint64_t>() + reinterpret_cast<uintptr_t>(pars[k].segmap);
+      pars[k].segentry = d->d_segidx.as<uint32_t>() + reinterpret_cast<uintptr_t>(pars[k].segentry);
+      pars[k].segbase = pars[k].segentry + pars[k].nseg + 1;
+      imgs[k].par = d->d_par.as<ParImage>() + k;
+    }
+  }
   for (uint32_t k = 0; k < m; k++) {
     imgs[k].aux = d->d_aux.as<uint32_t>() + reinterpret_cast<uintptr_t>(imgs[k].aux);
     imgs[k].scratch = d->d_scratch.as<uint32_t>() + reinterpret_cast<uintptr_t>(imgs[k].scratch);
@@ -1041,12 +1445,26 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
       !hip_ok(hipMemcpyAsync(sbf, sb_first.data(), (m + 1) * 4, hipMemcpyHostToDevice, s), "upload table") ||
       !hip_ok(hipMemsetAsync(dres, 0, m * sizeof(DecResult), s), "clear results"))
     return VP8L_ERR_HIP;
+  if (whole_device &&
+      (!hip_ok(hipMemcpyAsync(d->d_par.ptr, pars.data(), m * sizeof(ParImage), hipMemcpyHostToDevice, s), "upload segment workspace") ||
+       !hip_ok(hipMemcpyAsync(d->d_segfirst.ptr, seg_first.data(), (m + 1) * 4, hipMemcpyHostToDevice, s), "upload segment table")))
+    return VP8L_ERR_HIP;
   const uint32_t gunits = (uint32_t)(sb_total * kUnitsPerSuper);
   (void)hipEventRecord(d->ev0, s);
   // A workgroup per stream decodes one stream several times faster than a wave per stream; the waves only win
   // with thousands of small streams of noisy content, so they are an option, not the default.
   if (d->threads_per_stream == 64) hipLaunchKernelGGL(k_decode_entropy, dim3(m), dim3(64), 0, s, dimgs, dres);
   else hipLaunchKernelGGL(k_decode_entropy_wg, dim3(m), dim3(kWgThreads), 0, s, dimgs, dres);
+  if (whole_device) {
+    // streams whose main image k_decode_entropy_wg left to the segment kernels (the others are finished: these kernels pass them by)
+    const uint32_t *segf = d->d_segfirst.as<uint32_t>();
+    hipLaunchKernelGGL(k_par_maps, dim3((uint32_t)seg_total), dim3(kWgThreads), 0, s, dimgs, segf, m);
+    hipLaunchKernelGGL(k_par_chain, dim3(m), dim3(256), 0, s, dimgs);
+    hipLaunchKernelGGL(k_par_pixels, dim3((uint32_t)seg_total), dim3(kWgThreads), 0, s, dimgs, segf, m);
+    for (uint32_t pass = 0; pass < kParJumpPasses; pass++) hipLaunchKernelGGL(k_par_jump, dim3(gunits), dim3(256), 0, s, dimgs, sbf, m, pass);
+    hipLaunchKernelGGL(k_par_gather, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m);
+    hipLaunchKernelGGL(k_par_finish, dim3(m), dim3(1), 0, s, dimgs, dres);
+  }
   for (uint32_t pass = 0; pass < 4; pass++) {
     hipLaunchKernelGGL(k_inverse_stash, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m, pass);
     hipLaunchKernelGGL(k_inverse_pointwise, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m, pass);
@@ -1084,26 +1502,42 @@ extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8
     }
     pending.push_back((uint32_t)i);
   }
+  // The segment kernels (one stream spread over the device) pay when there are fewer streams than CUs and
+  // enough stream bytes to make segments for all of them: they decode about 2.7 GP/s of photo-like content
+  // whatever the number of streams, a workgroup per stream 17 MP/s times the number of streams (up to 256).
+  uint64_t stream_bytes = 0;
+  for (uint32_t i : pending) stream_bytes += len[i];
+  bool whole_device = d->threads_per_stream != 64 &&
+                      (d->whole_device == 2 || (d->whole_device == 0 && pending.size() <= 128 && stream_bytes >= (2u << 20)));
+  d->last_whole_device = 0;
   uint32_t group_cap = 4;
   while (!pending.empty()) {
     std::vector<DecResult> results;
-    const int rc = decode_pass(d, pending, d_data, len, width, height, d_argb, group_cap, results);
+    const int rc = decode_pass(d, pending, d_data, len, width, height, d_argb, group_cap, whole_device, results);
     if (rc != VP8L_OK) return rc;
     std::vector<uint32_t> again;
-    uint32_t need = 0;
+    uint32_t need = group_cap;
+    bool fell_back = false;
     for (size_t k = 0; k < pending.size(); k++) {
       const DecResult &r = results[k];
       if (r.status == kErrWorkspace && r.need_groups > group_cap) {
         again.push_back(pending[k]);  // a stream with more Huffman groups than this pass provided
         need = std::max(need, r.need_groups);
+      } else if (r.status == kParFallback || r.status == kParPending) {
+        again.push_back(pending[k]);  // a stream the segment kernels handed back: the one-workgroup form decodes it
+        fell_back = true;
       } else {
         status[pending[k]] = r.status;
+        if (whole_device && r.nxf <= 4 && r.pad == 1) d->last_whole_device++;
       }
     }
     pending.swap(again);
     group_cap = need;
+    if (fell_back) whole_device = false;
   }
   return VP8L_OK;
 }
+
+extern "C" long vp8l_decoder_last_whole_device_streams(const vp8l_decoder *d) { return d ? (long)d->last_whole_device : 0; }
 
 extern "C" double vp8l_decoder_last_device_seconds(const vp8l_decoder *d) { return d ? d->last_seconds : 0.0; }
