@@ -63,6 +63,8 @@ int vp8l_decode(const uint8_t *data, size_t len, uint32_t **argb, uint32_t *widt
 /* ReadInfo (vp8l.h:83-94) on the host: dimensions from the first 9 bytes. */
 int vp8l_get_info(const uint8_t *data, size_t len, uint32_t *width, uint32_t *height);
 
+/* Releases a result of the host-memory entry points (never free() them: they are page-locked blocks, which the
+ * library keeps for later calls, up to VP8L_HOST_POOL_MB megabytes, default 2048; 0 = ordinary malloc'ed memory). */
 void vp8l_free(void *p);
 
 /* ---- batches, host memory ----------------------------------------------------------------

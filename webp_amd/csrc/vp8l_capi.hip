@@ -76,6 +76,66 @@ const size_t g_chunk_bytes = (size_t)env_int("VP8L_HOST_CHUNK_MB", 64, 1, 4096) 
 const size_t g_decode_chunk_streams = (size_t)env_int("VP8L_HOST_DECODE_STREAMS", 256, 1, 1 << 20);
 constexpr size_t kDecodeChunkMaxBytes = (size_t)8 << 30;
 
+// Results handed to the caller live in page-locked host memory: a download into freshly allocated ordinary
+// memory runs at 3-4 GB/s (first-touch page faults under a staged copy), into page-locked memory at the link's
+// 50+ GB/s.  Page-locking is slow itself, so blocks given back through vp8l_free are kept for the next call
+// (up to VP8L_HOST_POOL_MB, default 2048; 0 = plain malloc, nothing kept).
+class HostPool {
+ public:
+  void *get(size_t bytes) {
+    const size_t want = (std::max<size_t>(bytes, 1) + kGrain - 1) & ~(kGrain - 1);
+    if (cap_ == 0) return malloc(want);
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      auto it = idle_.lower_bound(want);
+      if (it != idle_.end() && it->first <= 2 * want) {  // close enough in size
+        void *p = it->second;
+        idle_bytes_ -= it->first;
+        live_[p] = it->first;
+        idle_.erase(it);
+        return p;
+      }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) {
+      (void)hipGetLastError();
+      return malloc(want);  // not tracked: put() says no and the caller frees it
+    }
+    std::lock_guard<std::mutex> lock(mu_);
+    live_[p] = want;
+    return p;
+  }
+  bool put(void *p) {
+    size_t size = 0;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      auto it = live_.find(p);
+      if (it == live_.end()) return false;
+      size = it->second;
+      live_.erase(it);
+      if (idle_bytes_ + size <= cap_) {
+        idle_.emplace(size, p);
+        idle_bytes_ += size;
+        return true;
+      }
+    }
+    (void)hipHostFree(p);
+    return true;
+  }
+
+ private:
+  static constexpr size_t kGrain = 64 << 10;
+  std::mutex mu_;
+  std::map<void *, size_t> live_;
+  std::multimap<size_t, void *> idle_;
+  size_t idle_bytes_ = 0;
+  const size_t cap_ = (size_t)env_int("VP8L_HOST_POOL_MB", 2048, 0, 1 << 20) << 20;
+};
+HostPool &host_pool() {
+  static HostPool *p = new HostPool;  // intentionally leaked: HIP may be gone at exit
+  return *p;
+}
+
 struct Lane {
   vp8l_encoder *enc = nullptr;
   vp8l_decoder *dec = nullptr;
@@ -218,7 +278,9 @@ extern "C" const char *vp8l_status_string(int status) {
 
 extern "C" const char *vp8l_last_error(void) { return last_error_slot().c_str(); }
 
-extern "C" void vp8l_free(void *p) { free(p); }
+extern "C" void vp8l_free(void *p) {
+  if (p && !host_pool().put(p)) free(p);
+}
 
 extern "C" int vp8l_get_info(const uint8_t *data, size_t len, uint32_t *width, uint32_t *height) {
   if (!data || !width || !height) return VP8L_ERR_BAD_ARGUMENT;
@@ -277,7 +339,7 @@ int encode_batch_with(int device, int pred_bits, size_t n, const uint32_t *const
     for (size_t k = 0; k < m; k++) {
       const size_t i = i0 + k;
       if (status[i] != VP8L_OK) { out_len[i] = 0; continue; }
-      out[i] = static_cast<uint8_t *>(malloc(out_len[i] ? out_len[i] : 1));
+      out[i] = static_cast<uint8_t *>(host_pool().get(out_len[i]));
       if (!out[i]) { status[i] = VP8L_ERR_NO_MEMORY; out_len[i] = 0; continue; }
       if (!hip_ok(hipMemcpyAsync(out[i], lane.d_out.as<uint8_t>() + off[k], out_len[i], hipMemcpyDeviceToHost, lane.copy), "download stream"))
         return VP8L_ERR_HIP;
@@ -287,7 +349,7 @@ int encode_batch_with(int device, int pred_bits, size_t n, const uint32_t *const
   };
   rc = run_chunks(p, first.size() - 1, work);
   if (rc != VP8L_OK) {
-    for (size_t i = 0; i < n; i++) { free(out[i]); out[i] = nullptr; out_len[i] = 0; }
+    for (size_t i = 0; i < n; i++) { vp8l_free(out[i]); out[i] = nullptr; out_len[i] = 0; }
   }
   return rc;
 }
@@ -364,7 +426,7 @@ extern "C" int vp8l_decode_batch(int device, size_t n, const uint8_t *const *dat
       const size_t i = idx[k0 + k];
       status[i] = v_status[k];
       if (status[i] != VP8L_OK) continue;
-      argb[i] = static_cast<uint32_t *>(malloc(bytes[k0 + k]));
+      argb[i] = static_cast<uint32_t *>(host_pool().get(bytes[k0 + k]));
       if (!argb[i]) { status[i] = VP8L_ERR_NO_MEMORY; continue; }
       if (!hip_ok(hipMemcpyAsync(argb[i], d_argb[k], bytes[k0 + k], hipMemcpyDeviceToHost, lane.copy), "download image")) return VP8L_ERR_HIP;
     }
@@ -373,7 +435,7 @@ extern "C" int vp8l_decode_batch(int device, size_t n, const uint8_t *const *dat
   };
   rc = run_chunks(p, first.size() - 1, work);
   if (rc != VP8L_OK) {
-    for (size_t i = 0; i < n; i++) { free(argb[i]); argb[i] = nullptr; }
+    for (size_t i = 0; i < n; i++) { vp8l_free(argb[i]); argb[i] = nullptr; }
   }
   return rc;
 }
