@@ -65,6 +65,177 @@ def cpu_baseline(w, h, plan, threads, budget_images):
     }
 
 
+# ---------------------------------------------------------------------------------------------
+# The other BASELINE configurations (not the headline line; same JSON shape, one line each).
+# ---------------------------------------------------------------------------------------------
+def _fence(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _encode_batch_on_device(enc, d_in, ws, hs, dev):
+    batch = d_in.shape[0]
+    cap = sum(enc.bound(w, h) for w, h in zip(ws, hs))
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    ptrs = [d_in[k].data_ptr() for k in range(batch)]
+    return d_out, ptrs
+
+
+def _timed_steps(args, world, dev, step, units_per_step):
+    for _ in range(args.warmup):
+        step()
+    _fence(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _fence(world)
+    elapsed = time.perf_counter() - t0
+    return sharding.global_throughput(units_per_step * args.steps, elapsed, dev)
+
+
+def _base_line(args, world, metric, value, elapsed, workload, extra):
+    out = {"metric": metric, "value": value, "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u32", "data": "synthetic", "config": {"workload": workload, "parallelism": "images sharded over %d GPU(s), no collective" % world}}
+    out.update(extra)
+    return out
+
+
+def workload_decode1080p(args, world, rank, local_rank, dev):
+    """BASELINE configs[3]: 4096 1920x1080 streams over 8 GPUs = 512 per GPU, half photo-like, half graphics."""
+    w, h, batch = 1920, 1080, 512
+    npx = w * h
+    webp_amd.init()
+    d_in = torch.empty((batch, npx), dtype=torch.int32, device=dev)
+    plan = [(3 if k % 2 == 0 else 4, 12345 + rank * batch + k) for k in range(batch)]
+    for k, (mode, seed) in enumerate(plan):
+        webp_amd.generate_device(mode, w, h, seed, 0, d_in[k].data_ptr(), device=local_rank)
+    enc = webp_amd.Encoder(local_rank)
+    ws, hs = [w] * batch, [h] * batch
+    d_out, ptrs = _encode_batch_on_device(enc, d_in, ws, hs, dev)
+    off, lens, status = enc.encode_device(ptrs, ws, hs, d_out.data_ptr(), d_out.numel())
+    assert (status == 0).all()
+    dec = webp_amd.Decoder(local_rank)
+    d_dec = torch.empty((batch, npx), dtype=torch.int32, device=dev)
+    dargs = ([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], ws, hs, [d_dec[k].data_ptr() for k in range(batch)])
+    dev_times = []
+
+    def step():
+        st = dec.decode_device(*dargs)
+        assert (st == 0).all()
+        dev_times.append(dec.last_device_seconds())
+
+    total_px, elapsed = _timed_steps(args, world, dev, step, batch * npx)
+    ok = bool(torch.equal(d_dec, d_in))
+    if rank != 0:
+        return None
+    bpp = 8.0 * float(lens.sum()) / (batch * npx)
+    dev_s = float(np.mean(dev_times[args.warmup:]))
+    alg = (bpp / 8.0 + 4.0) * batch * npx  # stream bytes read + pixels written
+    out = _base_line(args, world, "vp8l_decode_megapixels_per_sec", total_px / 1e6 / elapsed, elapsed,
+                     "batch of %d synthetic %dx%d streams per rank (half photo-like, half graphics), VP8L decode "
+                     "(BASELINE configs[3] = 4096 streams over 8 GPUs); streams and pixels resident in HBM" % (batch, w, h),
+                     {"bits_per_pixel": bpp, "roundtrip_verified": ok, "device_ms_per_step": 1e3 * dev_s,
+                      "roofline": {"kernel": "decode path (k_decode_entropy_wg + inverse transforms)", "bound": "hbm",
+                                   "achieved": alg / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dev_s / 1e9 / HBM_PEAK_GBS,
+                                   "traffic": None, "algorithmic_bytes_per_launch": alg}})
+    out["cpu_baseline"] = None
+    if world == 1 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle as O
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        sample = [bytes(d_out[int(off[k]):int(off[k]) + int(lens[k])].cpu().numpy()) for k in range(threads)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            rcs = list(ex.map(lambda s: O.decode(s)[0], sample))
+        dt = time.perf_counter() - t0
+        assert all(r == 0 for r in rcs)
+        out["cpu_baseline"] = {"value": len(sample) * npx / 1e6 / dt, "unit": "MP/s", "cores": threads, "kind": "port",
+                               "sample": "%d of the benchmark's streams, one per host thread, %.1f s wall" % (len(sample), dt)}
+    return out
+
+
+def _encode_workload(args, world, rank, local_rank, dev, w, h, plan, workload, metric="vp8l_encode_megapixels_per_sec"):
+    batch = len(plan)
+    npx = w * h
+    webp_amd.init()
+    d_in = torch.empty((batch, npx), dtype=torch.int32, device=dev)
+    for k, (mode, seed, ncol) in enumerate(plan):
+        webp_amd.generate_device(mode, w, h, seed, ncol, d_in[k].data_ptr(), device=local_rank)
+    enc = webp_amd.Encoder(local_rank)
+    ws, hs = [w] * batch, [h] * batch
+    d_out, ptrs = _encode_batch_on_device(enc, d_in, ws, hs, dev)
+    res = {}
+    dev_times, stage_acc = [], {}
+
+    def step():
+        res["r"] = enc.encode_device(ptrs, ws, hs, d_out.data_ptr(), d_out.numel())
+        assert (res["r"][2] == 0).all()
+        dev_times.append(enc.last_device_seconds())
+        for k2, v in enc.last_stage_seconds().items():
+            stage_acc[k2] = stage_acc.get(k2, 0.0) + v
+
+    total_px, elapsed = _timed_steps(args, world, dev, step, batch * npx)
+    off, lens, status = res["r"]
+    ok, dec_ms = None, None
+    if not args.no_verify:
+        dec = webp_amd.Decoder(local_rank)
+        d_dec = torch.empty((batch, npx), dtype=torch.int32, device=dev)
+        dargs = ([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], ws, hs, [d_dec[k].data_ptr() for k in range(batch)])
+        dec.decode_device(*dargs)
+        st = dec.decode_device(*dargs)
+        dec_ms = 1e3 * dec.last_device_seconds()
+        ok = bool((st == 0).all() and torch.equal(d_dec, d_in))
+    if rank != 0:
+        return None
+    bpp = 8.0 * float(lens.sum()) / (batch * npx)
+    dev_s = float(np.mean(dev_times[args.warmup:]))
+    alg = (4.0 + bpp / 8.0) * batch * npx  # the fused ideal: every pixel read once, the stream written once
+    n = len(dev_times)
+    out = _base_line(args, world, metric, total_px / 1e6 / elapsed, elapsed, workload,
+                     {"bits_per_pixel": bpp, "roundtrip_verified": ok, "decode_device_ms": dec_ms, "device_ms_per_step": 1e3 * dev_s,
+                      "stage_ms_per_step": {k2: 1e3 * v / n for k2, v in stage_acc.items()},
+                      "roofline": {"kernel": "whole encode path", "bound": "hbm", "achieved": alg / dev_s / 1e9, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": alg / dev_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                   "algorithmic_bytes_per_launch": alg}})
+    out["cpu_baseline"] = None
+    if world == 1 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle as O
+        O.lib()
+        mode, seed, ncol = plan[0]
+        sw, sh = (w, h) if npx <= (1 << 23) else (4096, 2048)  # a bounded sample of the same content
+        img = O.gen_image(mode, sw, sh, seed, ncol or 200)
+        t0 = time.perf_counter()
+        rc, data = O.encode(img, sw, sh)
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        out["cpu_baseline"] = {"value": sw * sh / 1e6 / dt, "unit": "MP/s", "cores": 1, "kind": "port",
+                               "sample": "one %dx%d image of the first image's content on one host thread, %.1f s" % (sw, sh, dt)}
+    return out
+
+
+def workload_palette2k(args, world, rank, local_rank, dev):
+    """BASELINE configs[4]: 1024 2048x2048 palette images over 8 GPUs = 128 per GPU; 2, 4, 16 and 200 colours in turn."""
+    plan = [(5, 777 + rank * 128 + k, (2, 4, 16, 200)[k % 4]) for k in range(128)]
+    return _encode_workload(args, world, rank, local_rank, dev, 2048, 2048, plan,
+                            "batch of 128 synthetic 2048x2048 palette images per rank (2/4/16/200 colours), colour indexing + pixel "
+                            "bundling + VP8L encode (BASELINE configs[4] = 1024 images over 8 GPUs); inputs and streams resident in HBM")
+
+
+def workload_single16k(args, world, rank, local_rank, dev):
+    """BASELINE configs[2]: one 16383x16383 image on one GPU (every rank encodes its own: replicas)."""
+    plan = [(4, 4242 + rank, 0)]
+    return _encode_workload(args, world, rank, local_rank, dev, 16383, 16383, plan,
+                            "one synthetic 16383x16383 graphics image per rank (maximum VP8L size), VP8L encode (BASELINE configs[2]); "
+                            "input and stream resident in HBM")
+
+
+OTHER_WORKLOADS = {"decode1080p": workload_decode1080p, "palette2k": workload_palette2k, "single16k": workload_single16k}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +248,8 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=0, help="images in the CPU-baseline sample (0 = one per thread)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--workload", default="encode4k", choices=sorted(OTHER_WORKLOADS) + ["encode4k"],
+                    help="encode4k = BASELINE configs[1] (the headline line); the others measure configs[2..4]")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,6 +259,14 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+    if args.workload != "encode4k":
+        out = OTHER_WORKLOADS[args.workload](args, world, rank, local_rank, dev)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     w, h, batch = args.width, args.height, args.batch
     npx = w * h

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-stage device times of the encoder for one kind of synthetic content (development aid).
 
-usage: stage_probe.py MODE [BATCH] [W] [H] [--exhaustive] [--predictor=BITS]"""
+usage: stage_probe.py MODE [BATCH] [W] [H] [--exhaustive] [--predictor=BITS] [--colors=N] [--dec-threads=N] [--whole-device=N]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,10 +10,14 @@ import webp_amd
 pos = [a for a in sys.argv[1:] if not a.startswith("--")]
 mode = int(pos[0]); batch = int(pos[1]) if len(pos) > 1 else 64
 w = int(pos[2]) if len(pos) > 2 else 3840; h = int(pos[3]) if len(pos) > 3 else 2160
+ncolors = 200
+for a in sys.argv:
+    if a.startswith("--colors="):
+        ncolors = int(a.split("=")[1])
 webp_amd.init()
 d_in = torch.empty((batch, w * h), dtype=torch.int32, device="cuda")
 for k in range(batch):
-    webp_amd.generate_device(mode, w, h, 12345 + k, 200, d_in[k].data_ptr())
+    webp_amd.generate_device(mode, w, h, 12345 + k, ncolors, d_in[k].data_ptr())
 enc = webp_amd.Encoder()
 if "--exhaustive" in sys.argv:
     enc.set_exhaustive_search(True)
