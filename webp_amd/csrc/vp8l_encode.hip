@@ -463,6 +463,8 @@ constexpr uint32_t kSpTagShift = kSpPosBits;         // ... the remaining low bi
 constexpr uint32_t kSpMul = 0x9E3779B1u;             // odd: x -> x * kSpMul is a bijection on 32 bits, so
                                                      // same bucket + same tag <=> same pixel value
 constexpr uint32_t kSpMaxBucket = 192;   // a bucket this full means heavy duplication: not a sparse tile
+constexpr uint32_t kSpHeavyBucket = 24;  // no bucket this full: the tile is sparse, no need to count its values
+constexpr uint32_t kSpMaxPerValue = 6;   // more run starts per distinct value than this on average: not a sparse tile
 constexpr uint32_t kSpBudget = 700;      // candidate tests + extension steps one thread may spend (4 positions)
 constexpr uint32_t kSpSeg = 7;           // window pixels per thread in the run-length pass
 static_assert(kSpSources <= (1u << kSpPosBits) && kSpSources % kSpThreads == 0 && kSpTile % kSpThreads == 0, "entry layout");
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   __shared__ uint32_t items[kSpSources];   // (low bits of the mixed pixel) << 11 | index in px
   __shared__ uint32_t wsum[kSpWaves];
   __shared__ uint32_t wmin[kSpWaves];
-  __shared__ uint32_t s_abort, s_inside;
+  __shared__ uint32_t s_abort, s_inside, s_nonempty, s_heavy;
   constexpr uint32_t kPerSuper = kSuper / kSpTile;
   // Workgroups go round-robin to the 8 XCDs, each with its own L2.  Neighbouring tiles share half of their
   // window, so every XCD takes one contiguous eighth of the tiles: the overlap is then read from its L2, not twice from HBM.
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   const uint32_t *data = pix + pos0;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   for (uint32_t i = tid; i < kSpBuckets; i += kSpThreads) cursor[i] = 0;
-  if (tid == 0) { s_abort = 0; s_inside = 0; }
+  if (tid == 0) { s_abort = 0; s_inside = 0; s_nonempty = 0; s_heavy = 0; }
   // lo is a multiple of 4 (a and kWindow are) and the pixel array has readable slack past M: 16-byte loads
   if (st[img].fused) {
     // Subtract-green path: the residual is made here from the caller's pixels (vp8l.h:594-597,
@@ -586,10 +588,24 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   const uint32_t incl = wave_incl_scan_u32(sum, (int)lane);
   if (lane == 63) wsum[wave] = incl;
   if (mx > kSpMaxBucket) s_abort = 1;
+  if (mx >= kSpHeavyBucket) s_heavy = 1;
   __syncthreads();
   if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
   uint32_t run = incl - sum;
   for (uint32_t k = 0; k < wave; k++) run += wsum[k];
+  if (s_heavy) {
+    // Some value is frequent.  Many entries of few values (two-colour noise bundled eight pixels to a word, 16 colours
+    // two to a word): every position has dozens of candidates that extend a little, and the exhaustive kernel is
+    // cheaper than finding that out by running out of budget.  Counted on the scalar unit; other tiles skip this.
+    uint32_t nz = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) nz += (uint32_t)__popcll(__ballot(c[k] != 0));
+    if (lane == 0 && nz) atomicAdd(&s_nonempty, nz);
+    __syncthreads();
+    uint32_t entries = 0;
+    for (uint32_t k = 0; k < kSpWaves; k++) entries += wsum[k];
+    if (entries > kSpMaxPerValue * s_nonempty) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
+  }
 #pragma unroll
   for (int k = 0; k < 8; k++) { cursor[tid * 8 + k] = run; run += c[k]; }
   __syncthreads();
