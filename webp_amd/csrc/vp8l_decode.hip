@@ -789,7 +789,10 @@ constexpr uint32_t kParWindowWords = kParSegBits / 32 + 16;
 constexpr uint32_t kParStop = 0x7f, kParNone = 0xff;   // exit codes next to the bit offsets 0..63
 constexpr uint32_t kParMinPixels = 1u << 16;            // smaller images are not worth the extra passes
 constexpr uint32_t kParJumpPasses = 32;
-constexpr int32_t kParPending = 1, kParFallback = 2;    // DecResult.status values that are not verdicts
+constexpr int32_t kParPending = 1, kParFallback = 2, kParRetryMaps = 3;  // DecResult.status values that are not verdicts
+constexpr uint32_t kParWarm = 4096;                   // stream bits a scout decodes before its segment to fall in step with the token chain
+constexpr uint32_t kParScoutWords = (kParSegBits + kParWarm) / 32 + 16;
+constexpr uint32_t kParRecCap = 8192;                  // token records per segment (8 bytes each: 8 times the segment's stream bytes)
 constexpr uint32_t kFinalBit = 0x80000000u;             // in the per-pixel source array: this position holds its final value
 
 struct ParImage {
@@ -799,6 +802,8 @@ struct ParImage {
   uint32_t *segentry;  // nseg + 1: bit offset at which the chain enters the segment
   uint32_t *segbase;   // nseg + 1: first pixel of the segment (>= total: nothing left for it)
   uint32_t nseg;
+  uint32_t mode;       // 1: scouts and token records, 2: entry maps (see below)
+  uint64_t *records;   // mode 1: nseg * kParRecCap token records: value | pixels << 32 | is-reference << 40
   // set on the device
   uint32_t active;
   int32_t status;
@@ -810,10 +815,80 @@ struct ParImage {
   GroupTables tables;
 };
 
+__device__ __forceinline__ uint64_t par_window_bits(const VP8L_LDS uint32_t *win, uint32_t a) {  // 64 stream bits from bit a of the window
+  const uint32_t idx = a >> 5, sft = a & 31u;
+  const uint64_t x = (uint64_t)win[idx] | ((uint64_t)win[idx + 1] << 32);
+  return sft ? (x >> sft) | ((uint64_t)win[idx + 2] << (64 - sft)) : x;
+}
+
 __device__ __forceinline__ void par_fail(ParImage *par, int32_t code) {
-  // a fallback wins over a verdict (the one-workgroup form then gives the verdict); among verdicts the first stays
+  // handing the stream to another form wins over a verdict (that form then gives the verdict); among verdicts the first stays
   if (code == kParFallback) atomicExch(&par->status, code);
+  else if (code == kParRetryMaps) { atomicCAS(&par->status, (int32_t)kOk, code); atomicCAS(&par->status, (int32_t)kErrInvalidVp8l, code); }
   else atomicCAS(&par->status, (int32_t)kOk, code);
+}
+
+// One round of the workgroup decoder without its output stage: the tokens at window bits a + tid (tid < lim; the
+// others end the chain), the chain from offset 0, and for every token on it the pixels and tokens before it.
+// Leaves sh.end_off (bits the round consumed) set after the caller's next barrier; pixels made = r.all_px.
+struct WgRound {
+  uint32_t hop, cnt, val, ex, rank, all_px, all_tok;
+  bool ref, on;
+};
+__device__ __forceinline__ void wg_round(VP8L_LDS uint32_t *win, uint32_t a, uint32_t lim, const VP8L_LDS GroupTables &g, VP8L_LDS WgShared &sh,
+                                         uint32_t xsize, uint32_t tid, WgRound &r) {
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  r.hop = 0; r.cnt = 0; r.val = 0; r.ref = false;
+  if (tid < lim) wg_token(par_window_bits(win, a + tid), g, sh, xsize, r.hop, r.cnt, r.val, r.ref);
+  uint32_t s1[kWgLevels], s2[kWgLevels], s3[kWgLevels];
+  s1[0] = r.hop && tid + r.hop < kWgSpan ? tid + r.hop : kWgSpan;
+  sh.ja[tid] = (uint16_t)s1[0];
+  sh.mark[tid] = tid == 0 ? (uint8_t)(kWgLevels + 1) : (uint8_t)0;
+  if (tid == 0) { sh.ja[kWgSpan] = (uint16_t)kWgSpan; sh.jb[kWgSpan] = (uint16_t)kWgSpan; }
+  VP8L_LDS uint16_t *cur = sh.ja, *oth = sh.jb;
+#pragma unroll
+  for (uint32_t k = 0; k < kWgLevels; k++) {
+    __syncthreads();
+    s2[k] = cur[s1[k]];
+    s3[k] = cur[s2[k]];
+    if (k + 1 < kWgLevels) {
+      s1[k + 1] = cur[s3[k]];
+      oth[tid] = (uint16_t)s1[k + 1];
+      VP8L_LDS uint16_t *t16 = cur; cur = oth; oth = t16;
+    }
+  }
+  const uint32_t beyond = s2[kWgLevels - 1];
+#pragma unroll
+  for (int k = (int)kWgLevels - 1; k >= 0; k--) {
+    if (k != (int)kWgLevels - 1) __syncthreads();
+    if (sh.mark[tid] > (uint32_t)k + 1) {
+      sh.mark[s1[k]] = (uint8_t)(k + 1);
+      if (k != (int)kWgLevels - 1) {
+        sh.mark[s2[k]] = (uint8_t)(k + 1);
+        sh.mark[s3[k]] = (uint8_t)(k + 1);
+      }
+    }
+  }
+  __syncthreads();
+  r.on = sh.mark[tid] != 0;
+  const uint32_t c = r.on && r.hop ? r.cnt | (1u << 16) : 0u;  // pixels (at most 128 * 255) and tokens (at most 128) in one scan
+  const uint32_t incl = wave_incl_scan_u32(c, (int)lane);
+  if (lane == 63) sh.wsum[wave] = incl;
+  if (tid == 0) { sh.defer_off = 0xffffffffu; sh.end_off = 0; sh.end_px = 0; }
+  __syncthreads();
+  const uint32_t wsums = wave_incl_scan_u32(lane < kWgWaves ? sh.wsum[lane] : 0u, (int)lane);
+  const uint32_t before = wave ? lane_read(wsums, wave - 1) : 0u, all = lane_read(wsums, kWgWaves - 1);
+  const uint32_t exc = before + incl - c;
+  r.ex = exc & 0xffffu;
+  r.rank = exc >> 16;
+  r.all_px = all & 0xffffu;
+  r.all_tok = all >> 16;
+  // where the round ends: after the last token of the chain, at a token the round cannot take, or after 128 tokens
+  if (tid == 0 && beyond != kWgSpan) sh.end_off = beyond;
+  if (r.on) {
+    if (r.hop == 0) sh.end_off = tid;
+    else if (s1[0] == kWgSpan) sh.end_off = tid + r.hop;
+  }
 }
 
 // Tables and long-code lists into LDS, the segment's stream bytes into the window.  Returns the window's first bit.
@@ -829,11 +904,6 @@ __device__ __forceinline__ uint64_t par_setup(VP8L_LDS GroupTables &g, VP8L_LDS 
   return lo * 8;
 }
 
-__device__ __forceinline__ uint64_t par_window_bits(const VP8L_LDS uint32_t *win, uint32_t a) {  // 64 stream bits from bit a of the window
-  const uint32_t idx = a >> 5, sft = a & 31u;
-  const uint64_t x = (uint64_t)win[idx] | ((uint64_t)win[idx + 1] << 32);
-  return sft ? (x >> sft) | ((uint64_t)win[idx + 2] << (64 - sft)) : x;
-}
 
 __global__ __launch_bounds__(kWgThreads) void k_par_maps(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ segfirst, uint32_t n) {
   __shared__ GroupTables g;
@@ -844,7 +914,7 @@ __global__ __launch_bounds__(kWgThreads) void k_par_maps(const DecImage *__restr
   const uint32_t img = find_image(segfirst, n, blockIdx.x), seg = blockIdx.x - segfirst[img];
   const DecImage im = imgs[img];
   ParImage *par = im.par;
-  if (!par || !par->active || seg >= par->nseg) return;
+  if (!par || !par->active || par->mode != 2 || seg >= par->nseg) return;
   const uint64_t bit0 = par_setup((VP8L_LDS GroupTables &)g, (VP8L_LDS WgShared &)sh, (VP8L_LDS uint32_t *)win, im, par, seg, tid);
   const uint32_t first = (uint32_t)(par->P0 + (uint64_t)seg * kParSegBits - bit0), xsize = par->xsize;
   const uint64_t sink = (uint64_t)kWgSpan | ((uint64_t)kParNone << 16);
@@ -890,7 +960,7 @@ __global__ __launch_bounds__(256) void k_par_chain(const DecImage *__restrict__ 
   __shared__ uint64_t chunk[kChunk * 64];
   const uint32_t tid = threadIdx.x;
   ParImage *par = imgs[blockIdx.x].par;
-  if (!par || !par->active) return;
+  if (!par || !par->active || par->mode != 2) return;
   const uint32_t nseg = par->nseg, total = par->total;
   uint32_t e = 0;
   uint64_t base = 0;
@@ -929,7 +999,7 @@ __global__ __launch_bounds__(kWgThreads) void k_par_pixels(const DecImage *__res
   const uint32_t img = find_image(segfirst, n, blockIdx.x), seg = blockIdx.x - segfirst[img];
   const DecImage im = imgs[img];
   ParImage *par = im.par;
-  if (!par || !par->active || seg >= par->nseg || par->status != kOk) return;
+  if (!par || !par->active || par->mode != 2 || seg >= par->nseg || par->status != kOk) return;
   const uint32_t total = par->total, xsize = par->xsize;
   uint32_t fill = par->segbase[seg];
   if (fill >= total) return;
@@ -1050,6 +1120,161 @@ __global__ __launch_bounds__(kWgThreads) void k_par_pixels(const DecImage *__res
     // the chain of this segment must end exactly where the next one starts
     else if (fill < total && P != P_end) par_fail(par, kParFallback);
   }
+}
+
+
+// ---- mode 1: scouts.  A Huffman-coded stream falls in step by itself: a decoder started at a wrong bit almost
+// always lands on a true token start within a few tokens and stays on the chain from then on.  A scout starts
+// kParWarm bits before its segment, records every token of its segment (value, pixels, kind) once, and says where it
+// entered and left the segment; k_par_verify accepts the records only if every scout entered where its predecessor
+// left (segment 0 starts at the true position, so by induction all of them were on the true chain).  If one was not
+// (codes of one length never fall in step), the stream is decoded again with the entry maps of mode 2.
+__global__ __launch_bounds__(kWgThreads) void k_par_scout(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ segfirst, uint32_t n) {
+  __shared__ GroupTables g_;
+  __shared__ uint32_t win_[kParScoutWords];
+  __shared__ __attribute__((aligned(16))) WgShared sh_;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t img = find_image(segfirst, n, blockIdx.x), seg = blockIdx.x - segfirst[img];
+  const DecImage im = imgs[img];
+  ParImage *par = im.par;
+  if (!par || !par->active || par->mode != 1 || seg >= par->nseg) return;
+  VP8L_LDS GroupTables &g = (VP8L_LDS GroupTables &)g_;
+  VP8L_LDS WgShared &sh = (VP8L_LDS WgShared &)sh_;
+  VP8L_LDS uint32_t *win = (VP8L_LDS uint32_t *)win_;
+  for (uint32_t i = tid; i < sizeof(GroupTables) / 4; i += kWgThreads)
+    reinterpret_cast<VP8L_LDS uint32_t *>(&g)[i] = reinterpret_cast<const uint32_t *>(&par->tables)[i];
+  const uint64_t sb = par->P0 + (uint64_t)seg * kParSegBits;  // seg >= 1: sb - kParWarm >= P0
+  const uint32_t warm = seg ? kParWarm : 0;
+  const uint64_t lo = ((sb - warm) >> 3) & ~3ull;
+  wg_window_load(win, im, lo, tid, kParScoutWords);
+  __syncthreads();
+  wg_prepare_long(sh, g, tid);
+  __syncthreads();
+  const uint32_t xsize = par->xsize;
+  const uint32_t seg_start = (uint32_t)(sb - lo * 8), seg_end = seg_start + kParSegBits;  // window bit positions
+  uint32_t P = seg_start - warm;
+  WgRound r;
+  while (P < seg_start) {  // falling in step: nothing is kept
+    __syncthreads();
+    wg_round(win, P, seg_start - P, g, sh, xsize, tid, r);
+    __syncthreads();
+    const uint32_t adv = sh.end_off;
+    P += adv ? adv : 1;  // a token this decoder cannot take at a position that need not be a token start: try the next bit
+  }
+  const uint32_t entry = P - seg_start;
+  uint64_t *rec = par->records + (size_t)seg * kParRecCap;
+  uint32_t ntok = 0, npx = 0, flags = 0;
+  while (P < seg_end) {
+    __syncthreads();
+    wg_round(win, P, seg_end - P, g, sh, xsize, tid, r);
+    if (r.on && r.hop) {
+      const uint32_t i = ntok + r.rank;
+      if (i < kParRecCap) rec[i] = (uint64_t)r.val | ((uint64_t)r.cnt << 32) | ((uint64_t)(r.ref ? 1u : 0u) << 40);
+    }
+    __syncthreads();
+    const uint32_t adv = sh.end_off;
+    ntok += r.all_tok;
+    npx += r.all_px;
+    if (adv == 0) { flags |= 1; break; }  // a token the round decoder cannot take: the stream goes to the one-workgroup form
+    P += adv;
+  }
+  if (ntok > kParRecCap) flags |= 2;
+  if (tid == 0) {
+    uint64_t *slot = par->segmap + (size_t)seg * 64;
+    slot[0] = (uint64_t)(P - seg_end) | ((uint64_t)npx << 32);
+    slot[1] = (uint64_t)entry | ((uint64_t)ntok << 32);
+    slot[2] = flags;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_par_verify(const DecImage *__restrict__ imgs) {
+  constexpr uint32_t kChunk = 256;
+  __shared__ uint64_t s0[kChunk], s1[kChunk], s2[kChunk];
+  const uint32_t tid = threadIdx.x;
+  ParImage *par = imgs[blockIdx.x].par;
+  if (!par || !par->active || par->mode != 1) return;
+  const uint32_t nseg = par->nseg, total = par->total;
+  uint32_t expect = 0;  // thread 0: where the chain enters the next segment
+  uint64_t base = 0;
+  int32_t verdict = kOk;
+  for (uint32_t g0 = 0; g0 < nseg; g0 += kChunk) {
+    const uint32_t cnt = nseg - g0 < kChunk ? nseg - g0 : kChunk;
+    if (tid < cnt) {
+      const uint64_t *slot = par->segmap + (size_t)(g0 + tid) * 64;
+      s0[tid] = slot[0]; s1[tid] = slot[1]; s2[tid] = slot[2];
+    }
+    __syncthreads();
+    if (tid == 0 && verdict == kOk) {
+      for (uint32_t k = 0; k < cnt; k++) {
+        if (base >= total) { par->segbase[g0 + k] = total; continue; }
+        if (((uint32_t)s1[k] & 0xffu) != expect) { verdict = kParRetryMaps; break; }  // this scout was not on the chain
+        if (s2[k] & 2) { verdict = kParRetryMaps; break; }                             // more tokens than records
+        par->segbase[g0 + k] = (uint32_t)base;
+        base += s0[k] >> 32;
+        if ((s2[k] & 1) && base < total) { verdict = kParFallback; break; }
+        expect = (uint32_t)s0[k] & 0xffu;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (verdict == kOk && base < total) verdict = kParFallback;  // the stream ends before the image does
+    if (verdict != kOk) par_fail(par, verdict);
+  }
+}
+
+__global__ __launch_bounds__(kWgThreads) void k_par_place(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ segfirst, uint32_t n) {
+  __shared__ uint32_t wsum[kWgWaves];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t img = find_image(segfirst, n, blockIdx.x), seg = blockIdx.x - segfirst[img];
+  ParImage *par = imgs[img].par;
+  if (!par || !par->active || par->mode != 1 || seg >= par->nseg || par->status != kOk) return;
+  const uint32_t total = par->total;
+  uint32_t fill = par->segbase[seg];
+  if (fill >= total) return;
+  const uint32_t ntok = (uint32_t)(par->segmap[(size_t)seg * 64 + 1] >> 32);
+  const uint64_t *rec = par->records + (size_t)seg * kParRecCap;
+  uint32_t *dst = par->dst, *srcg = par->srcg;
+  bool bad = false;
+  for (uint32_t t0 = 0; t0 < ntok && fill < total; t0 += kWgThreads) {
+    const uint32_t i = t0 + tid;
+    const uint64_t rc = i < ntok ? rec[i] : 0ull;
+    const uint32_t val = (uint32_t)rc, cnt = (uint32_t)(rc >> 32) & 0xffu;
+    const bool ref = (rc >> 40) & 1ull;
+    const uint32_t incl = wave_incl_scan_u32(cnt, (int)lane);
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    const uint32_t wsums = wave_incl_scan_u32(lane < kWgWaves ? wsum[lane] : 0u, (int)lane);
+    const uint32_t before = wave ? lane_read(wsums, wave - 1) : 0u, all = lane_read(wsums, kWgWaves - 1);
+    const uint32_t pos = fill + before + incl - cnt;
+    bool expand = false;
+    if (cnt && pos < total) {
+      if (pos + cnt > total) bad = true;        // a reference that runs past the end of the image
+      else if (!ref) { dst[pos] = val; srcg[pos] = pos | kFinalBit; }
+      else if (val > pos) bad = true;           // a reference before the start of the image
+      else expand = true;
+    }
+    if (expand && cnt <= kWgOwnCopy) {
+      if (val >= cnt) {
+        for (uint32_t e = 0; e < cnt; e++) srcg[pos + e] = pos - val + e;
+      } else {
+        for (uint32_t e = 0; e < cnt; e++) srcg[pos + e] = pos - val + e % val;
+      }
+    }
+    uint64_t m = __ballot(expand && cnt > kWgOwnCopy);
+    while (m) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(m);
+      m &= m - 1;
+      const uint32_t p2 = lane_read(pos, l), n2 = lane_read(cnt, l), dist = lane_read(val, l);
+      for (uint32_t c2 = 0; c2 < n2; c2 += 64) {
+        const uint32_t e = c2 + lane;
+        if (e < n2) srcg[p2 + e] = p2 - dist + (dist < n2 ? e % dist : e);
+      }
+    }
+    fill += all;
+  }
+  if (bad) par_fail(par, kErrInvalidVp8l);
 }
 
 // sb_first / units as for the inverse transforms: a unit of kUnit pixels per workgroup
@@ -1316,7 +1541,7 @@ struct vp8l_decoder {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
   DeviceBuffer d_imgs, d_res, d_sbfirst, d_aux, d_scratch, d_groups, d_cache, d_sorted;
-  DeviceBuffer d_par, d_srcg, d_segmap, d_segidx, d_segfirst;  // the segment kernels' workspace
+  DeviceBuffer d_par, d_srcg, d_segmap, d_segidx, d_segfirst, d_records;  // the segment kernels' workspace
   double last_seconds = 0;
   int threads_per_stream = 0;  // 0: chosen per call
   int whole_device = 0;        // 0: chosen per call, 1: never, 2: whenever the stream qualifies
@@ -1360,7 +1585,7 @@ extern "C" void vp8l_decoder_destroy(vp8l_decoder *d) {
   if (d->ev0) (void)hipEventDestroy(d->ev0);
   if (d->ev1) (void)hipEventDestroy(d->ev1);
   DeviceBuffer *bufs[] = {&d->d_imgs, &d->d_res, &d->d_sbfirst, &d->d_aux, &d->d_scratch, &d->d_groups, &d->d_cache, &d->d_sorted,
-                          &d->d_par, &d->d_srcg, &d->d_segmap, &d->d_segidx, &d->d_segfirst};
+                          &d->d_par, &d->d_srcg, &d->d_segmap, &d->d_segidx, &d->d_segfirst, &d->d_records};
   for (auto *b : bufs) b->release();
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
@@ -1370,8 +1595,9 @@ namespace {
 
 // One pass over the images listed in `idx` with `group_cap` multi-group table sets per image.
 int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t *const *d_data, const size_t *len,
-                const uint32_t *width, const uint32_t *height, uint32_t *const *d_argb, uint32_t group_cap, bool whole_device,
+                const uint32_t *width, const uint32_t *height, uint32_t *const *d_argb, uint32_t group_cap, int whole_mode,
                 std::vector<DecResult> &results) {
+  const bool whole_device = whole_mode != 0;  // 1: scouts and records, 2: entry maps
   const uint32_t m = (uint32_t)idx.size();
   std::vector<DecImage> imgs(m);
   std::vector<uint32_t> sb_first(m + 1, 0), seg_first(m + 1, 0);
@@ -1400,6 +1626,8 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
       const uint64_t nseg = ((uint64_t)len[i] * 8 + kParSegBits - 1) / kParSegBits + 1;
       memset(&pars[k], 0, sizeof(ParImage));
       pars[k].nseg = (uint32_t)nseg;
+      pars[k].mode = (uint32_t)whole_mode;
+      pars[k].records = reinterpret_cast<uint64_t *>(seg_total * kParRecCap);
       pars[k].srcg = reinterpret_cast<uint32_t *>(px_total);  // offsets for now
       pars[k].segmap = reinterpret_cast<uint64_t *>(seg_total * 64);
       pars[k].segentry = reinterpret_cast<uint32_t *>((seg_total + k) * 2);
@@ -1420,9 +1648,11 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
   if (!ok) return VP8L_ERR_NO_MEMORY;
   if (whole_device) {
     if (!d->d_par.reserve(m * sizeof(ParImage)) || !d->d_srcg.reserve(px_total * 4) || !d->d_segmap.reserve(seg_total * 64 * 8) ||
-        !d->d_segidx.reserve((seg_total + m) * 2 * 4) || !d->d_segfirst.reserve((m + 1) * 4))
+        !d->d_segidx.reserve((seg_total + m) * 2 * 4) || !d->d_segfirst.reserve((m + 1) * 4) ||
+        (whole_mode == 1 && !d->d_records.reserve(seg_total * kParRecCap * 8)))
       return VP8L_ERR_NO_MEMORY;
     for (uint32_t k = 0; k < m; k++) {
+      pars[k].records = whole_mode == 1 ? d->d_records.as<uint64_t>() + reinterpret_cast<uintptr_t>(pars[k].records) : nullptr;
       pars[k].srcg = d->d_srcg.as<uint32_t>() + reinterpret_cast<uintptr_t>(pars[k].srcg);
       pars[k].segmap = d->d_segmap.as<uint64_t>() + reinterpret_cast<uintptr_t>(pars[k].segmap);
       pars[k].segentry = d->d_segidx.as<uint32_t>() + reinterpret_cast<uintptr_t>(pars[k].segentry);
@@ -1458,9 +1688,15 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
   if (whole_device) {
     // streams whose main image k_decode_entropy_wg left to the segment kernels (the others are finished: these kernels pass them by)
     const uint32_t *segf = d->d_segfirst.as<uint32_t>();
-    hipLaunchKernelGGL(k_par_maps, dim3((uint32_t)seg_total), dim3(kWgThreads), 0, s, dimgs, segf, m);
-    hipLaunchKernelGGL(k_par_chain, dim3(m), dim3(256), 0, s, dimgs);
-    hipLaunchKernelGGL(k_par_pixels, dim3((uint32_t)seg_total), dim3(kWgThreads), 0, s, dimgs, segf, m);
+    if (whole_mode == 1) {
+      hipLaunchKernelGGL(k_par_scout, dim3((uint32_t)seg_total), dim3(kWgThreads), 0, s, dimgs, segf, m);
+      hipLaunchKernelGGL(k_par_verify, dim3(m), dim3(256), 0, s, dimgs);
+      hipLaunchKernelGGL(k_par_place, dim3((uint32_t)seg_total), dim3(kWgThreads), 0, s, dimgs, segf, m);
+    } else {
+      hipLaunchKernelGGL(k_par_maps, dim3((uint32_t)seg_total), dim3(kWgThreads), 0, s, dimgs, segf, m);
+      hipLaunchKernelGGL(k_par_chain, dim3(m), dim3(256), 0, s, dimgs);
+      hipLaunchKernelGGL(k_par_pixels, dim3((uint32_t)seg_total), dim3(kWgThreads), 0, s, dimgs, segf, m);
+    }
     for (uint32_t pass = 0; pass < kParJumpPasses; pass++) hipLaunchKernelGGL(k_par_jump, dim3(gunits), dim3(256), 0, s, dimgs, sbf, m, pass);
     hipLaunchKernelGGL(k_par_gather, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m);
     hipLaunchKernelGGL(k_par_finish, dim3(m), dim3(1), 0, s, dimgs, dres);
@@ -1510,30 +1746,35 @@ extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8
   bool whole_device = d->threads_per_stream != 64 &&
                       (d->whole_device == 2 || (d->whole_device == 0 && pending.size() <= 128 && stream_bytes >= (2u << 20)));
   d->last_whole_device = 0;
-  uint32_t group_cap = 4;
-  while (!pending.empty()) {
+  // Passes: first everything (whole-device streams with scouts), then again what a pass handed on: streams whose
+  // scouts were not in step (entry maps), streams the segment kernels cannot take (one workgroup), streams with more
+  // Huffman groups than the pass provided.
+  struct Todo { std::vector<uint32_t> idx; int mode; uint32_t group_cap; };
+  std::vector<Todo> todo;
+  todo.push_back({pending, whole_device ? 1 : 0, 4});
+  while (!todo.empty()) {
+    Todo t = std::move(todo.back());
+    todo.pop_back();
     std::vector<DecResult> results;
-    const int rc = decode_pass(d, pending, d_data, len, width, height, d_argb, group_cap, whole_device, results);
+    const int rc = decode_pass(d, t.idx, d_data, len, width, height, d_argb, t.group_cap, t.mode, results);
     if (rc != VP8L_OK) return rc;
-    std::vector<uint32_t> again;
-    uint32_t need = group_cap;
-    bool fell_back = false;
-    for (size_t k = 0; k < pending.size(); k++) {
+    Todo more_groups{{}, t.mode, t.group_cap}, with_maps{{}, 2, t.group_cap}, one_workgroup{{}, 0, t.group_cap};
+    for (size_t k = 0; k < t.idx.size(); k++) {
       const DecResult &r = results[k];
-      if (r.status == kErrWorkspace && r.need_groups > group_cap) {
-        again.push_back(pending[k]);  // a stream with more Huffman groups than this pass provided
-        need = std::max(need, r.need_groups);
-      } else if (r.status == kParFallback || r.status == kParPending) {
-        again.push_back(pending[k]);  // a stream the segment kernels handed back: the one-workgroup form decodes it
-        fell_back = true;
+      if (r.status == kErrWorkspace && r.need_groups > t.group_cap) {
+        more_groups.idx.push_back(t.idx[k]);
+        more_groups.group_cap = std::max(more_groups.group_cap, r.need_groups);
+      } else if (r.status == kParRetryMaps && t.mode == 1) {
+        with_maps.idx.push_back(t.idx[k]);
+      } else if (r.status == kParFallback || r.status == kParPending || r.status == kParRetryMaps) {
+        one_workgroup.idx.push_back(t.idx[k]);
       } else {
-        status[pending[k]] = r.status;
-        if (whole_device && r.nxf <= 4 && r.pad == 1) d->last_whole_device++;
+        status[t.idx[k]] = r.status;
+        if (t.mode && r.pad == 1) d->last_whole_device++;
       }
     }
-    pending.swap(again);
-    group_cap = need;
-    if (fell_back) whole_device = false;
+    for (Todo *n2 : {&more_groups, &with_maps, &one_workgroup})
+      if (!n2->idx.empty()) todo.push_back(std::move(*n2));
   }
   return VP8L_OK;
 }
