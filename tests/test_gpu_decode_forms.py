@@ -131,7 +131,7 @@ def handmade_cases():
     def lits(n):
         return [("lit", int(g)) for g in rng.integers(0, 232, size=n)]
 
-    w, h = 4096, 8
+    w, h = 4096, 16  # large enough for the whole-device form
     total = w * h
     toks = lits(3000) + [("ref", 1000, 2900), ("ref", 4096, 1), ("ref", 200, 3000), ("ref", 255, 5)] + lits(70)
     toks += [("ref", 256, 8000), ("ref", 3, 2), ("ref", 2500, 2049), ("ref", 1, 1)] + lits(5) + [("ref", 128, 2048), ("ref", 128, 2047)]
@@ -262,3 +262,23 @@ def test_whole_device_handmade_tokens():
         assert st == rc0, (st, rc0)
         if rc0 == 0:
             assert np.array_equal(px, ref)
+
+
+def test_whole_device_when_scouts_cannot_fall_in_step():
+    """Uniform random 7-bit values give codes of one length: a decoder started at a wrong bit never meets the token chain,
+    so the scouts are rejected and the entry maps decode the stream; same pixels.  (All 256 byte values would give the
+    256 x 8-bit code that the reference itself cannot read back.)"""
+    rng = np.random.default_rng(2)
+    w, h = 768, 512
+    img = rng.integers(0, 1 << 32, size=w * h, dtype=np.uint32) & 0x7F7F7F7F
+    img2 = (img & 0x003F1F7F) | 0xFF000000
+    streams = []
+    for im in (img, img2):
+        rc, s = O.encode(im, w, h)
+        assert rc == 0
+        streams.append(s)
+    used = []
+    res = decode_with(1024, streams, whole_device=2, used=used)
+    for (st, px), im in zip(res, (img, img2)):
+        assert st == 0 and np.array_equal(px, im)
+    assert used[0] == 2, used
