@@ -995,7 +995,7 @@ __global__ __launch_bounds__(kWgThreads) void k_par_pixels(const DecImage *__res
   __shared__ GroupTables g_;
   __shared__ uint32_t win_[kParWindowWords];
   __shared__ __attribute__((aligned(16))) WgShared sh_;
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t img = find_image(segfirst, n, blockIdx.x), seg = blockIdx.x - segfirst[img];
   const DecImage im = imgs[img];
   ParImage *par = im.par;
@@ -1015,76 +1015,17 @@ __global__ __launch_bounds__(kWgThreads) void k_par_pixels(const DecImage *__res
   uint32_t *dst = par->dst, *srcg = par->srcg;
   if (tid == 0) sh.status = kOk;
   int32_t status = kOk;
+  WgRound r;
   while (P < P_end && fill < total) {
     __syncthreads();
-    const uint32_t lim = P_end - P;  // offsets from here on belong to the next segment
-    uint32_t hop = 0, cnt = 0, val = 0;
-    bool ref = false;
-    if (tid < lim) wg_token(par_window_bits(win, P + tid), g, sh, xsize, hop, cnt, val, ref);
-    // ---- the chain from offset 0, as in wg_decode_pixels
-    uint32_t s1[kWgLevels], s2[kWgLevels], s3[kWgLevels];
-    s1[0] = hop && tid + hop < kWgSpan ? tid + hop : kWgSpan;
-    sh.ja[tid] = (uint16_t)s1[0];
-    sh.mark[tid] = tid == 0 ? (uint8_t)(kWgLevels + 1) : (uint8_t)0;
-    if (tid == 0) { sh.ja[kWgSpan] = (uint16_t)kWgSpan; sh.jb[kWgSpan] = (uint16_t)kWgSpan; }
-    VP8L_LDS uint16_t *cur = sh.ja, *oth = sh.jb;
-#pragma unroll
-    for (uint32_t k = 0; k < kWgLevels; k++) {
-      __syncthreads();
-      s2[k] = cur[s1[k]];
-      s3[k] = cur[s2[k]];
-      if (k + 1 < kWgLevels) {
-        s1[k + 1] = cur[s3[k]];
-        oth[tid] = (uint16_t)s1[k + 1];
-        VP8L_LDS uint16_t *t16 = cur; cur = oth; oth = t16;
-      }
-    }
-    const uint32_t beyond = s2[kWgLevels - 1];
-#pragma unroll
-    for (int k = (int)kWgLevels - 1; k >= 0; k--) {
-      if (k != (int)kWgLevels - 1) __syncthreads();
-      if (sh.mark[tid] > (uint32_t)k + 1) {
-        sh.mark[s1[k]] = (uint8_t)(k + 1);
-        if (k != (int)kWgLevels - 1) {
-          sh.mark[s2[k]] = (uint8_t)(k + 1);
-          sh.mark[s3[k]] = (uint8_t)(k + 1);
-        }
-      }
-    }
-    __syncthreads();
-    const bool on = sh.mark[tid] != 0;
-    const uint32_t c = on && hop ? cnt : 0u;
-    const uint32_t incl = wave_incl_scan_u32(c, (int)lane);
-    if (lane == 63) sh.wsum[wave] = incl;
-    if (tid == 0) { sh.defer_off = 0xffffffffu; sh.end_off = 0; sh.end_px = 0; }
-    __syncthreads();
-    const uint32_t wsums = wave_incl_scan_u32(lane < kWgWaves ? sh.wsum[lane] : 0u, (int)lane);
-    const uint32_t before = wave ? lane_read(wsums, wave - 1) : 0u, all = lane_read(wsums, kWgWaves - 1);
-    const uint32_t ex = before + incl - c, room = total - fill;
-    if (tid == 0 && beyond != kWgSpan) { sh.end_off = beyond; sh.end_px = all; }
+    wg_round(win, P, P_end - P, g, sh, xsize, tid, r);  // offsets from P_end on belong to the next segment
+    const uint32_t pos = fill + r.ex, cnt = r.cnt, val = r.val;
     bool expand = false;
-    const uint32_t pos = fill + ex;
-    if (on) {
-      if (hop == 0) {
-        sh.end_off = tid;
-        sh.end_px = ex;
-      } else {
-        if (s1[0] == kWgSpan) { sh.end_off = tid + hop; sh.end_px = ex + cnt; }
-        if (ex + cnt > room) {
-          if (ex <= room) {
-            sh.defer_off = tid;
-            sh.defer_px = ex;
-            if (ex < room) sh.status = kErrInvalidVp8l;  // a reference that runs past the end of the image
-          }
-        } else if (!ref) {
-          dst[pos] = val;
-          srcg[pos] = pos | kFinalBit;
-        } else if (val > pos) {
-          sh.status = kErrInvalidVp8l;  // a reference before the start of the image
-        } else {
-          expand = true;
-        }
-      }
+    if (r.on && r.hop && pos < total) {  // tokens past the last pixel are not the image's
+      if (pos + cnt > total) sh.status = kErrInvalidVp8l;  // a reference that runs past the end of the image
+      else if (!r.ref) { dst[pos] = val; srcg[pos] = pos | kFinalBit; }
+      else if (val > pos) sh.status = kErrInvalidVp8l;     // a reference before the start of the image
+      else expand = true;
     }
     // pixels that references make: only where their values come from, to be resolved by k_par_jump
     if (expand && cnt <= kWgOwnCopy) {
@@ -1094,25 +1035,22 @@ __global__ __launch_bounds__(kWgThreads) void k_par_pixels(const DecImage *__res
         for (uint32_t e = 0; e < cnt; e++) srcg[pos + e] = pos - val + e % val;
       }
     }
-    {
-      uint64_t m = __ballot(expand && cnt > kWgOwnCopy);
-      while (m) {
-        const uint32_t l = (uint32_t)__builtin_ctzll(m);
-        m &= m - 1;
-        const uint32_t p2 = lane_read(pos, l), n2 = lane_read(cnt, l), dist = lane_read(val, l);
-        for (uint32_t c2 = 0; c2 < n2; c2 += 64) {
-          const uint32_t e = c2 + lane;
-          if (e < n2) srcg[p2 + e] = p2 - dist + (dist < n2 ? e % dist : e);
-        }
+    uint64_t m = __ballot(expand && cnt > kWgOwnCopy);
+    while (m) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(m);
+      m &= m - 1;
+      const uint32_t p2 = lane_read(pos, l), n2 = lane_read(cnt, l), dist = lane_read(val, l);
+      for (uint32_t c2 = 0; c2 < n2; c2 += 64) {
+        const uint32_t e = c2 + lane;
+        if (e < n2) srcg[p2 + e] = p2 - dist + (dist < n2 ? e % dist : e);
       }
     }
     __syncthreads();
     status = sh.status;
     if (status != kOk) break;
-    const bool deferred = sh.defer_off != 0xffffffffu;
-    const uint32_t adv = deferred ? sh.defer_off : sh.end_off, produced = deferred ? sh.defer_px : sh.end_px;
-    if (adv == 0 && produced == 0) { status = kParFallback; break; }  // not expected after k_par_maps found its way through
-    fill += produced;
+    const uint32_t adv = sh.end_off;
+    if (adv == 0) { status = kParFallback; break; }  // not expected after k_par_maps found its way through
+    fill += r.all_px;
     P += adv;
   }
   if (tid == 0) {
