@@ -49,9 +49,11 @@ const char *vp8l_last_error(void); /* thread-local text of the last HIP failure 
  * vp8l_encode replaces `VP8_LOSSLESS_ENCODER(argb, width, height)` + `get_bit_writer()`
  * (vp8l.h:585-615).  argb: width*height pixels 0xAARRGGBB, borrowed.  *out is allocated by the
  * library (release with vp8l_free) and holds *out_len bytes.  flags = 0 gives the reference encoder's bytes;
- * flags = 2..9 (VP8L_FLAG_PREDICTOR_BITS_MASK) adds the predictor transform with that tile size, see
- * VP8L_OPT_PREDICTOR_BITS below. */
+ * flags & VP8L_FLAG_PREDICTOR_BITS_MASK = 2..9 adds the predictor transform with that tile size, (flags &
+ * VP8L_FLAG_CROSS_COLOR_BITS_MASK) >> 4 = 2..9 the cross-colour transform, see VP8L_OPT_PREDICTOR_BITS and
+ * VP8L_OPT_CROSS_COLOR_BITS below. */
 #define VP8L_FLAG_PREDICTOR_BITS_MASK 0xFu
+#define VP8L_FLAG_CROSS_COLOR_BITS_MASK 0xF0u
 int vp8l_encode(const uint32_t *argb, uint32_t width, uint32_t height, uint8_t **out, size_t *out_len,
                 uint32_t flags);
 
@@ -96,12 +98,16 @@ int vp8l_encoder_encode_device(vp8l_encoder *enc, size_t n, const uint32_t *cons
 /* Options.  VP8L_OPT_MATCH_SEARCH: 0 (default) = candidate-list match search with the exhaustive
  * search as fallback for tiles with heavy duplication; 1 = exhaustive search everywhere.  Both give
  * identical streams; the option exists for verification and measurement. */
-enum { VP8L_OPT_MATCH_SEARCH = 1, VP8L_OPT_PREDICTOR_BITS = 2 };
+enum { VP8L_OPT_MATCH_SEARCH = 1, VP8L_OPT_PREDICTOR_BITS = 2, VP8L_OPT_CROSS_COLOR_BITS = 3 };
 /* VP8L_OPT_PREDICTOR_BITS: 0 (default) = the reference encoder's output (subtract green or colour indexing only,
  * vp8l.h:594-610).  2..9 = additionally apply the predictor transform (14 modes, one per tile of 2^bits pixels
  * a side, chosen per tile; the tile size grows until an image has at most 1024 tiles) in front of the same
  * coder.  The reference DECODER reads such streams (ReadTransform vp8l.h:111-121, transform.h:110-191); they
  * are much smaller for natural images but of course differ from the reference encoder's bytes. */
+/* VP8L_OPT_CROSS_COLOR_BITS: 0 (default) = none; 2..9 = apply the cross-colour transform (per tile of 2^bits pixels a
+ * side three multipliers that take green out of red and green and red out of blue; the tile size grows like the
+ * predictor's) after subtract green and the predictor transform, if any.  Read by the reference decoder
+ * (transform.h:192-218); pays on images whose channels are correlated by factors other than one. */
 int vp8l_encoder_set_option(vp8l_encoder *enc, int option, int value);
 /* Number of 2048-position tiles of the last call that needed the exhaustive search (and the total). */
 long vp8l_encoder_last_dense_tiles(vp8l_encoder *enc, long *total_tiles);
@@ -114,7 +120,8 @@ enum {
   VP8L_STAGE_HISTO = 2,    /* 5 x 280 uint32 (GREEN, RED, BLUE, ALPHA, DIST; unused tail zero)           */
   VP8L_STAGE_CODELEN = 3,  /* 5 x 280 uint8 code lengths                                                 */
   VP8L_STAGE_INFO = 4,     /* uint32[4]: ncolors (0 = subtract-green path), bundling bits, xsize, M     */
-  VP8L_STAGE_PRED_MODES = 5 /* uint32[3] tile bits, columns, rows, then one uint32 per tile (0 bytes: none) */
+  VP8L_STAGE_PRED_MODES = 5, /* uint32[3] tile bits, columns, rows, then one uint32 per tile (0 bytes: none) */
+  VP8L_STAGE_CROSS_ELEMS = 6 /* the same layout for the cross-colour elements                                */
 };
 long vp8l_encoder_fetch_stage(vp8l_encoder *enc, size_t image, int what, void *host_buf, size_t cap_bytes);
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-stage device times of the encoder for one kind of synthetic content (development aid).
 
-usage: stage_probe.py MODE [BATCH] [W] [H] [--exhaustive] [--predictor=BITS] [--colors=N] [--dec-threads=N] [--whole-device=N]"""
+usage: stage_probe.py MODE [BATCH] [W] [H] [--exhaustive] [--predictor=BITS] [--cross=BITS] [--colors=N] [--dec-threads=N] [--whole-device=N]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,6 +24,8 @@ if "--exhaustive" in sys.argv:
 for a in sys.argv:
     if a.startswith("--predictor="):
         enc.set_predictor_bits(int(a.split("=")[1]))
+    if a.startswith("--cross="):
+        enc.set_cross_color_bits(int(a.split("=")[1]))
 cap = enc.bound(w, h)
 d_out = torch.empty(batch * cap, dtype=torch.uint8, device="cuda")
 ptrs = [d_in[k].data_ptr() for k in range(batch)]

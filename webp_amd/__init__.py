@@ -27,7 +27,7 @@ STATUS_NAMES = {
     -5: "InvalidVP8L", -6: "InvalidHuffman", -7: "NoDevice", -8: "MemoryAllocationException", -9: "HipError",
     -10: "BadArgument", -11: "Workspace",
 }
-STAGE_RESIDUAL, STAGE_MATCH, STAGE_HISTO, STAGE_CODELEN, STAGE_INFO, STAGE_PRED_MODES = range(6)
+STAGE_RESIDUAL, STAGE_MATCH, STAGE_HISTO, STAGE_CODELEN, STAGE_INFO, STAGE_PRED_MODES, STAGE_CROSS_ELEMS = range(7)
 DEC_OPT_THREADS_PER_STREAM = 1
 DEC_OPT_WHOLE_DEVICE = 2
 ENCODE_STAGES = ("palette", "transform", "match", "parse", "histogram", "header", "bitcount_scan", "emit",
@@ -119,13 +119,13 @@ def init():
 
 
 # ------------------------------------------------------------------ host-memory forms
-def encode(argb, width, height, predictor_bits=0):
+def encode(argb, width, height, predictor_bits=0, cross_color_bits=0):
     """VP8_LOSSLESS_ENCODER(argb, width, height).get_bit_writer() -> stream bytes (vp8l.h:585-615).
     predictor_bits 2..9 adds the predictor transform (not the reference encoder's bytes any more)."""
     a = None if argb is None else np.ascontiguousarray(argb, dtype=np.uint32)
     out = C.c_void_p()
     n = C.c_size_t()
-    rc = lib().vp8l_encode(a.ctypes.data if a is not None and a.size else None, width, height, C.byref(out), C.byref(n), int(predictor_bits))
+    rc = lib().vp8l_encode(a.ctypes.data if a is not None and a.size else None, width, height, C.byref(out), C.byref(n), int(predictor_bits) | (int(cross_color_bits) << 4))
     if rc != OK:
         raise Vp8lError(rc, "vp8l_encode")
     data = C.string_at(out.value, n.value)
@@ -247,14 +247,15 @@ class Encoder:
             raise Vp8lError(int(rc), "vp8l_encoder_fetch_stage")
         if what == STAGE_INFO:
             return dict(ncolors=int(info[0]), bits=int(info[1]), xsize=int(info[2]), M=int(info[3]))
-        if what == STAGE_PRED_MODES:
+        if what in (STAGE_PRED_MODES, STAGE_CROSS_ELEMS):
             buf = np.zeros(3 + 1024, dtype=np.uint32)
             rc = lib().vp8l_encoder_fetch_stage(self._h, image, what, buf.ctypes.data, buf.nbytes)
             if rc < 0:
                 raise Vp8lError(int(rc), "vp8l_encoder_fetch_stage")
             if rc == 0:
                 return None
-            return dict(bits=int(buf[0]), tx=int(buf[1]), ty=int(buf[2]), modes=buf[3:3 + int(buf[1]) * int(buf[2])].copy())
+            tiles = buf[3:3 + int(buf[1]) * int(buf[2])].copy()
+            return dict(bits=int(buf[0]), tx=int(buf[1]), ty=int(buf[2]), modes=tiles, elems=tiles)
         if what in (STAGE_RESIDUAL, STAGE_MATCH):
             buf = np.zeros(int(info[3]), dtype=np.uint32)
         elif what == STAGE_HISTO:
@@ -278,6 +279,12 @@ class Encoder:
     def set_predictor_bits(self, bits):
         """0 (default): the reference encoder's output.  2..9: add the predictor transform, tiles of 2**bits."""
         rc = lib().vp8l_encoder_set_option(self._h, 2, int(bits))
+        if rc != OK:
+            raise Vp8lError(rc, "vp8l_encoder_set_option")
+
+    def set_cross_color_bits(self, bits):
+        """0 (default): none.  2..9: add the cross-colour transform, tiles of 2**bits (after subtract green / predictor)."""
+        rc = lib().vp8l_encoder_set_option(self._h, 3, int(bits))
         if rc != OK:
             raise Vp8lError(rc, "vp8l_encoder_set_option")
 

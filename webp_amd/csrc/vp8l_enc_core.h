@@ -354,6 +354,12 @@ VP8L_HD void write_predictor_head(BitSink &bw, uint32_t bits) {
   bw.put(0, 2);
   bw.put(bits - 2, 3);
 }
+// Cross-colour transform header (ReadTransform vp8l.h:111-121): present, type 1, tile bits - 2.
+VP8L_HD void write_cross_color_head(BitSink &bw, uint32_t bits) {
+  bw.put(1, 1);
+  bw.put(1, 2);
+  bw.put(bits - 2, 3);
+}
 VP8L_HD void write_stream_tail(BitSink &bw) {
   bw.put(0, 1);
   bw.put(0, 1);

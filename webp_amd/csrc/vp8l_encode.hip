@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void k_palette_scan(const EncImage *__restrict
 }
 
 __global__ __launch_bounds__(256) void k_palette_finalize(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
-                                                          const unsigned long long *__restrict__ gsets, uint32_t fuse, uint32_t pred_bits) {
+                                                          const unsigned long long *__restrict__ gsets, uint32_t fuse, uint32_t pred_bits,
+                                                          uint32_t cross_bits) {
   __shared__ uint32_t list[kSetSlots];
   __shared__ uint32_t s_k;
   const uint32_t img = blockIdx.x, tid = threadIdx.x;
@@ -122,6 +123,13 @@ __global__ __launch_bounds__(256) void k_palette_finalize(const EncImage *__rest
         s.pred_bits = b;
         s.pred_tx = (im.w + (1u << b) - 1) >> b;
         s.pred_ty = (im.h + (1u << b) - 1) >> b;
+      }
+      if (cross_bits) {
+        uint32_t b = cross_bits;
+        while (b < 9 && ((im.w + (1u << b) - 1) >> b) * ((im.h + (1u << b) - 1) >> b) > kSmallMax) b++;
+        s.cross_bits = b;
+        s.cross_tx = (im.w + (1u << b) - 1) >> b;
+        s.cross_ty = (im.h + (1u << b) - 1) >> b;
       }
     }
     return;
@@ -425,6 +433,108 @@ __global__ __launch_bounds__(256) void k_pred_residual(const EncImage *__restric
       P = predict(mode, L, src[p - w], x == w - 1 ? L : src[p - w + 1], src[p - w - 1]);
     }
     out[p] = px_sub(cur, P);
+  }
+}
+
+// =============================================================================================
+// Forward cross-colour transform (optional, like the predictor: the reference's decoder reads it, ReadTransform
+// vp8l.h:111-121, inverse transform.h:192-218).  Per tile three signed multipliers: red loses green * g2r / 32, blue
+// loses green * g2b / 32 and (original) red * r2b / 32.  A multiplier is found by a halving search (steps 32 ... 1 around
+// the best so far, from 0) on a rough bit cost of the residual bytes over up to 32 x 32 samples of the tile, and used only
+// if it takes an eighth off that sum, so tiles without correlation keep zeros, which cost next to nothing in the tile image.
+// An element is 0xff000000 | r2b << 16 | g2b << 8 | g2r (transform.h:29-34).
+// =============================================================================================
+__device__ __forceinline__ int32_t color_delta(int32_t t, int32_t c) { return (int32_t)(int8_t)((t * c) >> 5); }  // transform.h:192-195
+// What a residual byte costs, roughly: nothing for zero, else 1 + 2 * (bits of |v|), v taken modulo 256 as a signed byte.
+// (The plain sum of |v| prefers many small non-zero residuals to a few larger ones; the entropy coder does not.)
+__device__ __forceinline__ uint32_t abs_byte(int32_t v) {
+  const int32_t b = (int32_t)(int8_t)v;
+  const uint32_t a = (uint32_t)(b < 0 ? -b : b);
+  return a ? 1u + 2u * (32u - (uint32_t)__clz((int)a)) : 0u;
+}
+
+constexpr uint32_t kCrossPer = 32;  // up to 32 x 32 samples of a tile
+__global__ __launch_bounds__(64) void k_cross_elems(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                    const uint32_t *__restrict__ pix, uint32_t *__restrict__ elems) {
+  const uint32_t img = blockIdx.x / kSmallMax, tile = blockIdx.x % kSmallMax, lane = threadIdx.x;
+  const EncState &s = st[img];
+  const uint32_t bits = s.cross_bits;
+  if (bits == 0 || s.ncolors || tile >= s.cross_tx * s.cross_ty) return;
+  const uint32_t w = imgs[img].w, h = imgs[img].h;
+  const uint32_t *src = pix + imgs[img].pos0;
+  const uint32_t x0 = (tile % s.cross_tx) << bits, y0 = (tile / s.cross_tx) << bits, side = 1u << bits;
+  const uint32_t per = side < kCrossPer ? side : kCrossPer, step = side / per;  // samples per tile side and their spacing
+  constexpr uint32_t kMine = kCrossPer * kCrossPer / 64;
+  int32_t r[kMine], g[kMine], b[kMine];
+#pragma unroll
+  for (uint32_t k = 0; k < kMine; k++) {
+    const uint32_t i = k * 64 + lane, x = x0 + (i % per) * step, y = y0 + (i / per) * step;
+    r[k] = g[k] = b[k] = 0;  // a sample outside the tile or the image costs nothing whatever the multiplier
+    if (i < per * per && x < w && y < h) {
+      const uint32_t p = src[(uint64_t)y * w + x];
+      r[k] = (int32_t)(int8_t)(p >> 16);
+      g[k] = (int32_t)(int8_t)(p >> 8);
+      b[k] = (int32_t)(int8_t)p;
+    }
+  }
+  // cost of multiplier t for residual = base - delta(t, factor), summed over the tile's samples
+  auto search = [&](const int32_t *base, const int32_t *factor) -> int32_t {
+    auto cost = [&](int32_t t) {
+      uint32_t c = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kMine; k++) c += abs_byte(base[k] - color_delta(t, factor[k]));
+      return wave_sum_u32(c);
+    };
+    int32_t best = 0;
+    const uint32_t c0 = cost(0);
+    uint32_t bestc = c0;
+    for (int32_t stepv = 32; stepv >= 1; stepv >>= 1) {
+      const int32_t lo = best - stepv < -128 ? -128 : best - stepv, hi = best + stepv > 127 ? 127 : best + stepv;
+      const uint32_t cl = cost(lo), ch = cost(hi);
+      if (cl < bestc && cl <= ch) { bestc = cl; best = lo; }
+      else if (ch < bestc) { bestc = ch; best = hi; }
+    }
+    // The samples are a part of a large tile and the cost is not the entropy: a multiplier has to take an eighth off
+    // the sampled cost (and more than rounding noise) to be used, or it only stirs residuals that were already small.
+    return bestc + (c0 >> 3) + 32 <= c0 ? best : 0;
+  };
+  const int32_t g2r = search(r, g);
+  const int32_t g2b = search(b, g);
+  int32_t b2[kMine];
+#pragma unroll
+  for (uint32_t k = 0; k < kMine; k++) b2[k] = b[k] - color_delta(g2b, g[k]);
+  const int32_t r2b = search(b2, r);
+  if (lane == 0)
+    elems[(size_t)img * kSmallMax + tile] = 0xff000000u | ((uint32_t)(r2b & 0xff) << 16) | ((uint32_t)(g2b & 0xff) << 8) | (uint32_t)(g2r & 0xff);
+}
+
+// dst = src with the tiles' multipliers applied (cross-colour images) or a copy (all others); dst may be src
+__global__ __launch_bounds__(256) void k_cross_apply(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                     const uint32_t *__restrict__ sb_first, uint32_t n, const uint32_t *src_all,
+                                                     const uint32_t *__restrict__ elems, uint32_t *dst_all) {
+  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  const EncState &s = st[img];
+  const uint32_t M = s.M;
+  const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
+  if (p0 >= M) return;
+  const uint64_t pos0 = imgs[img].pos0;
+  const uint32_t *src = src_all + pos0;
+  uint32_t *out = dst_all + pos0;
+  const uint32_t bits = s.ncolors ? 0u : s.cross_bits, w = imgs[img].w;
+  if (bits == 0 && src == out) return;
+  const uint32_t *eimg = elems + (size_t)img * kSmallMax;
+  for (uint32_t k = 0; k < kUnit / 256; k++) {
+    const uint32_t p = p0 + k * 256 + tid;
+    if (p >= M) break;
+    const uint32_t cur = src[p];
+    if (bits == 0) { out[p] = cur; continue; }
+    const uint32_t y = p / w, x = p - y * w;
+    const uint32_t e = eimg[(y >> bits) * s.cross_tx + (x >> bits)];
+    const int32_t r2b = (int32_t)(int8_t)(e >> 16), g2b = (int32_t)(int8_t)(e >> 8), g2r = (int32_t)(int8_t)e;
+    const int32_t red = (int32_t)(int8_t)(cur >> 16), green = (int32_t)(int8_t)(cur >> 8);
+    const uint32_t nr = ((cur >> 16) - (uint32_t)color_delta(g2r, green)) & 0xffu;
+    const uint32_t nb = (cur - (uint32_t)color_delta(g2b, green) - (uint32_t)color_delta(r2b, red)) & 0xffu;
+    out[p] = (cur & 0xff00ff00u) | (nr << 16) | nb;
   }
 }
 
@@ -952,7 +1062,8 @@ __device__ __forceinline__ void build_codes_4waves(const uint32_t *histo5, CodeT
 // (palette matches, sorting) use the workgroup; the bits are written by one lane, in stream order.
 __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
                                                         const uint32_t *__restrict__ histo, CodeTables *__restrict__ tables,
-                                                        const uint32_t *__restrict__ modes, uint8_t *__restrict__ out) {
+                                                        const uint32_t *__restrict__ modes, const uint32_t *__restrict__ elems,
+                                                        uint8_t *__restrict__ out) {
   __shared__ HeaderShared sh;
   __shared__ BitSink bw;
   __shared__ int s_rc;
@@ -969,18 +1080,22 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
   }
   __syncthreads();
   HuffScratch &hs = wave == 0 ? sh.sub.desc.huff : sh.huff[wave - 1];
-  // A sub-image goes in front of the main image's codes: the palette as ncolors x 1 (vp8l.h:455-457), or the
-  // predictor modes as pred_tx x pred_ty (read by ReadTransform vp8l.h:111-121).
-  const uint32_t pred_bits = ncolors ? 0u : st[img].pred_bits;
-  const int np = ncolors ? (int)ncolors : pred_bits ? (int)(st[img].pred_tx * st[img].pred_ty) : 0;
-  const uint32_t sub_xsize = ncolors ? ncolors : st[img].pred_tx;
-  if (np) {
+  // Sub-images go in front of the main image's codes: the palette as ncolors x 1 (vp8l.h:455-457), or the predictor
+  // modes as pred_tx x pred_ty and then the cross-colour elements as cross_tx x cross_ty (read by ReadTransform
+  // vp8l.h:111-121), in the order the transforms were applied.
+  const uint32_t pred_bits = ncolors ? 0u : st[img].pred_bits, cross_bits = ncolors ? 0u : st[img].cross_bits;
+  for (int which = 0; which < 2; which++) {
+    const bool palette = which == 0 && ncolors, pred = which == 0 && pred_bits, cross = which == 1 && cross_bits;
+    if (!palette && !pred && !cross) continue;
+    const int np = palette ? (int)ncolors : pred ? (int)(st[img].pred_tx * st[img].pred_ty) : (int)(st[img].cross_tx * st[img].cross_ty);
+    const uint32_t sub_xsize = palette ? ncolors : pred ? st[img].pred_tx : st[img].cross_tx;
     uint32_t *d = sh.sub.delta;
-    if (ncolors) {
+    if (palette) {
       if (tid < ncolors) d[tid] = tid ? px_sub(sh.palette[tid], sh.palette[tid - 1]) : sh.palette[0];
     } else {
-      for (int i = (int)tid; i < np; i += 256) d[i] = modes[(size_t)img * kSmallMax + i];
-      if (tid == 0) write_predictor_head(bw, pred_bits);
+      const uint32_t *tiles = (pred ? modes : elems) + (size_t)img * kSmallMax;
+      for (int i = (int)tid; i < np; i += 256) d[i] = tiles[i];
+      if (tid == 0) { if (pred) write_predictor_head(bw, pred_bits); else write_cross_color_head(bw, cross_bits); }
     }
     __syncthreads();
     for (int p = (int)tid; p < np; p += 256) {  // best match of every position, same rules as small_best_matches
@@ -1003,7 +1118,7 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
     if (tid == 0) small_histogram(d, np, sub_xsize, sh.sub);
     __syncthreads();
     build_codes_4waves(sh.sub.histo, sh.sub.tables, sh.rc, hs, wave, lane);
-    if (tid == 0) {
+    if (tid == 0 && s_rc == 0) {
       bw.put(0, 1);  // no colour cache
       int rc = 0;
       for (int c = 0; c < kNumCodes && rc == 0; c++)
@@ -1388,10 +1503,12 @@ struct vp8l_encoder {
   std::mutex mu;
   // workspace (grown on demand)
   DeviceBuffer d_imgs, d_state, d_sbfirst, d_gsets, d_pix, d_match, d_flags, d_histo, d_tables, d_sx, d_entry,
-      d_unit_bits, d_unit_off, d_dense, d_group_bits, d_adv, d_pix2, d_modes;
+      d_unit_bits, d_unit_off, d_dense, d_group_bits, d_adv, d_pix2, d_modes, d_elems;
   int match_mode = 0;  // 0 = candidate lists with exhaustive fallback, 1 = exhaustive only
   const uint32_t *last_pix = nullptr;  // coded pixels of the last call (for fetch_stage)
   bool last_pred = false;
+  bool last_cross = false;
+  int cross_bits = 0;  // 0 = no cross-colour transform, else requested tile bits 2..9
   int pred_bits = 0;   // 0 = no predictor transform (the reference encoder's output), else requested tile bits 2..9
   // last batch
   std::vector<EncImage> imgs;
@@ -1429,7 +1546,7 @@ extern "C" void vp8l_encoder_destroy(vp8l_encoder *e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   DeviceBuffer *bufs[] = {&e->d_imgs, &e->d_state, &e->d_sbfirst, &e->d_gsets, &e->d_pix, &e->d_match, &e->d_flags,
-                          &e->d_histo, &e->d_tables, &e->d_sx, &e->d_entry, &e->d_unit_bits, &e->d_unit_off, &e->d_dense, &e->d_group_bits, &e->d_adv, &e->d_pix2, &e->d_modes};
+                          &e->d_histo, &e->d_tables, &e->d_sx, &e->d_entry, &e->d_unit_bits, &e->d_unit_off, &e->d_dense, &e->d_group_bits, &e->d_adv, &e->d_pix2, &e->d_modes, &e->d_elems};
   for (auto *b : bufs) b->release();
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -1491,7 +1608,8 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
             e->d_sx.reserve(sb_total * kBlockLen) && e->d_entry.reserve(sb_total) &&
             e->d_unit_bits.reserve(nunits * 4) && e->d_unit_off.reserve(nunits * 8) &&
             e->d_dense.reserve(sb_total * (kSuper / kLzTile)) && e->d_group_bits.reserve(npos / 16 * 2) && e->d_adv.reserve(npos) &&
-            (e->pred_bits == 0 || (e->d_pix2.reserve(npos * 4) && e->d_modes.reserve((size_t)nl * kSmallMax * 4)));
+            ((e->pred_bits == 0 && e->cross_bits == 0) ||
+             (e->d_pix2.reserve(npos * 4) && e->d_modes.reserve((size_t)nl * kSmallMax * 4) && e->d_elems.reserve((size_t)nl * kSmallMax * 4)));
   if (!ok) return VP8L_ERR_NO_MEMORY;
 
   hipStream_t s = e->stream;
@@ -1500,9 +1618,10 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   auto *sbf = e->d_sbfirst.as<uint32_t>();
   auto *gsets = e->d_gsets.as<unsigned long long>();
   auto *pix_t = e->d_pix.as<uint32_t>();                          // output of the pixel transform
-  const uint32_t pred = (uint32_t)e->pred_bits;
-  auto *pix = pred ? e->d_pix2.as<uint32_t>() : pix_t;            // what the match search and the coder read
-  auto *modes = pred ? e->d_modes.as<uint32_t>() : nullptr;
+  const uint32_t pred = (uint32_t)e->pred_bits, cross = (uint32_t)e->cross_bits;
+  auto *pix = (pred || cross) ? e->d_pix2.as<uint32_t>() : pix_t;  // what the match search and the coder read
+  auto *modes = (pred || cross) ? e->d_modes.as<uint32_t>() : nullptr;
+  auto *elems = (pred || cross) ? e->d_elems.as<uint32_t>() : nullptr;
   auto *match = e->d_match.as<uint32_t>();
   auto *flags = e->d_flags.as<uint32_t>();
   auto *histo = e->d_histo.as<uint32_t>();
@@ -1527,12 +1646,17 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   const uint32_t gsb = (uint32_t)sb_total, gunits = (uint32_t)nunits;
   (void)hipEventRecord(e->ev[0], s);
   hipLaunchKernelGGL(k_palette_scan, dim3(gsb), dim3(256), 0, s, imgs, st, sbf, nl, gsets);
-  hipLaunchKernelGGL(k_palette_finalize, dim3(nl), dim3(256), 0, s, imgs, st, gsets, (e->match_mode == 0 && !pred) ? 1u : 0u, pred);
+  hipLaunchKernelGGL(k_palette_finalize, dim3(nl), dim3(256), 0, s, imgs, st, gsets, (e->match_mode == 0 && !pred && !cross) ? 1u : 0u, pred, cross);
   (void)hipEventRecord(e->ev[1], s);
   hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix_t);
   if (pred) {
     hipLaunchKernelGGL(k_pred_modes, dim3(nl * kSmallMax), dim3(256), 0, s, imgs, st, pix_t, modes);
     hipLaunchKernelGGL(k_pred_residual, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix_t, modes, pix);
+  }
+  if (cross) {  // on what the predictor left (in place), or on the subtract-green image
+    const uint32_t *from = pred ? pix : pix_t;
+    hipLaunchKernelGGL(k_cross_elems, dim3(nl * kSmallMax), dim3(64), 0, s, imgs, st, from, elems);
+    hipLaunchKernelGGL(k_cross_apply, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, from, elems, pix);
   }
   (void)hipEventRecord(e->ev[2], s);
   if (e->match_mode == 0)
@@ -1548,7 +1672,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   (void)hipEventRecord(e->ev[4], s);
   hipLaunchKernelGGL(k_histogram, dim3(gsb), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, histo);
   (void)hipEventRecord(e->ev[5], s);
-  hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, imgs, st, histo, tables, modes, d_out);
+  hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, imgs, st, histo, tables, modes, elems, d_out);
   (void)hipEventRecord(e->ev[6], s);
   hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, gbits, ubits);
   hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, imgs, st, sbf, ubits, uoff, d_out);
@@ -1573,6 +1697,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   e->last_out = d_out;
   e->last_pix = pix;
   e->last_pred = pred != 0;
+  e->last_cross = cross != 0;
   for (uint32_t k = 0; k < nl; k++) {
     const size_t i = live[k];
     status[i] = e->states[k].status;
@@ -1612,6 +1737,14 @@ extern "C" long vp8l_encoder_fetch_stage(vp8l_encoder *e, size_t image, int what
       memcpy(host_buf, info, 12);
       if (!hip_ok(hipMemcpy(static_cast<uint8_t *>(host_buf) + 12, e->d_modes.as<uint32_t>() + slot * kSmallMax, bytes - 12, hipMemcpyDeviceToHost), "fetch modes")) return VP8L_ERR_HIP;
       return (long)bytes;
+    case VP8L_STAGE_CROSS_ELEMS:  // uint32[3] = bits, tile columns, tile rows; then one element per tile
+      if (!e->last_cross || st.ncolors || st.cross_bits == 0) return 0;
+      info[0] = st.cross_bits; info[1] = st.cross_tx; info[2] = st.cross_ty;
+      bytes = 12 + (size_t)st.cross_tx * st.cross_ty * 4;
+      if (bytes > cap) return VP8L_ERR_BAD_ARGUMENT;
+      memcpy(host_buf, info, 12);
+      if (!hip_ok(hipMemcpy(static_cast<uint8_t *>(host_buf) + 12, e->d_elems.as<uint32_t>() + slot * kSmallMax, bytes - 12, hipMemcpyDeviceToHost), "fetch elements")) return VP8L_ERR_HIP;
+      return (long)bytes;
     case VP8L_STAGE_MATCH: src = e->d_match.as<uint32_t>() + im.pos0; bytes = (size_t)st.M * 4; break;
     case VP8L_STAGE_HISTO: src = e->d_histo.as<uint32_t>() + slot * kNumCodes * kCodeStride; bytes = kNumCodes * kCodeStride * 4; break;
     case VP8L_STAGE_CODELEN: src = e->d_tables.as<CodeTables>()[slot].len; bytes = kNumCodes * kCodeStride; break;
@@ -1642,6 +1775,7 @@ extern "C" int vp8l_encoder_set_option(vp8l_encoder *e, int option, int value) {
   std::lock_guard<std::mutex> lock(e->mu);
   if (option == VP8L_OPT_MATCH_SEARCH && (value == 0 || value == 1)) { e->match_mode = value; return VP8L_OK; }
   if (option == VP8L_OPT_PREDICTOR_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->pred_bits = value; return VP8L_OK; }
+  if (option == VP8L_OPT_CROSS_COLOR_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->cross_bits = value; return VP8L_OK; }
   return VP8L_ERR_BAD_ARGUMENT;
 }
 

@@ -38,6 +38,9 @@ struct EncState {          // device-written
   uint32_t fused;          // the match kernel makes the subtract-green residual itself (k_transform skips the image)
   uint32_t pred_bits;      // predictor transform: tile size 2^bits (0 = none), pred_tx x pred_ty tiles
   uint32_t pred_tx, pred_ty;
+  uint32_t cross_bits;     // cross-colour transform: tile size 2^bits (0 = none), cross_tx x cross_ty tiles
+  uint32_t cross_tx, cross_ty;
+  uint32_t pad_cross;
   uint32_t hdr_bits;       // bits in front of the first token
   int32_t status;
   uint64_t total_bits;
