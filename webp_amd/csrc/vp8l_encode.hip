@@ -349,16 +349,16 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
 // Forward predictor transform (optional; the reference encoder has none, its decoder reads it:
 // ReadTransform vp8l.h:111-121, inverse transform.h:110-191).  Works on the subtract-green image.
 // The residual of a pixel needs only ORIGINAL neighbours, so it is one thread per pixel; the mode of
-// a tile is the one with the smallest sum of absolute residuals (bytes taken as signed), estimated
+// a tile is the one with the smallest rough bit cost of the residual bytes (taken as signed), estimated
 // on every second row and column of the tile.  Border rules as in the inverse: (0,0) predicts
 // 0xff000000, the first row predicts L, the first column T, and TR of the last column is L.
 // =============================================================================================
-__device__ __forceinline__ uint32_t abs_cost(uint32_t r) {  // sum over the four bytes of min(b, 256 - b)
+__device__ __forceinline__ uint32_t abs_cost(uint32_t r) {  // rough bit cost of the four residual bytes
   uint32_t c = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const uint32_t b = (r >> (8 * k)) & 0xff;
-    c += b < 128 ? b : 256 - b;
+    const uint32_t b = (r >> (8 * k)) & 0xff, a = b < 128 ? b : 256 - b;  // |byte| as a signed value
+    c += a ? 1u + 2u * (32u - (uint32_t)__clz((int)a)) : 0u;               // nothing for zero, else 1 + 2 * bits of |v|
   }
   return c;
 }
