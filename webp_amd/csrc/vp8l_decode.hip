@@ -1421,49 +1421,204 @@ __global__ __launch_bounds__(256) void k_inverse_pointwise(const DecImage *__res
 // Predictor inverse (transform.h:110-191).  Pixel (x,y) needs L, T, TL and TR = (x+1, y-1), so row y
 // may run two pixels behind row y-1: thread r of the block handles row y0+r and at step t the pixel
 // x = t - 2r.  One barrier per step; a band of `blockDim` rows at a time.
-__global__ __launch_bounds__(1024) void k_inverse_predictor(const DecImage *__restrict__ imgs, DecResult *__restrict__ res,
-                                                            uint32_t pass) {
-  const uint32_t img = blockIdx.x, r = threadIdx.x, R = blockDim.x;
+// Nothing on the step-to-step path touches HBM: the pixel a thread makes is handed to the thread below through
+// LDS (the row above's pixel x+1 is exactly what that thread made one step earlier; T and TL are the two hand-overs
+// before), residuals are fetched eight steps ahead into registers and staged in an LDS ring, the tile's mode is
+// fetched when the previous tile starts.  Only the finished pixels are stored to HBM.
+constexpr uint32_t kPredRows = 1024;
+__global__ __launch_bounds__(kPredRows) void k_inverse_predictor(const DecImage *__restrict__ imgs, DecResult *__restrict__ res,
+                                                                  uint32_t pass) {
+  __shared__ uint32_t hand[2][kPredRows + 1];  // hand[step parity][r + 1] = the pixel thread r made at that step; [0] = row above the band
+  __shared__ uint32_t ring[8][kPredRows];      // residuals of the current eight steps
+  __shared__ uint32_t upring[8];               // thread 0: pixels of the row above the band
+  const uint32_t img = blockIdx.x, r = threadIdx.x;
   XformRec xf;
   if (!pass_transform(res[img], pass, xf) || xf.type != 0) return;
   const DecImage im = imgs[img];
-  const uint32_t w = im.w, h = im.h;
+  const uint32_t w = im.w, h = im.h, bits = xf.bits, tmask = (1u << bits) - 1u;
   const uint32_t *modes = im.aux + xf.data_off;
   uint32_t *out = im.out;
   bool bad = false;
-  for (uint32_t y0 = 0; y0 < h; y0 += R) {
+  for (uint32_t y0 = 0; y0 < h; y0 += kPredRows) {
     const uint32_t y = y0 + r;
     const bool live = y < h;
-    uint32_t *row = out + (uint64_t)y * w;
-    const uint32_t *up = row - w;
+    uint32_t *row = out + (uint64_t)(live ? y : 0) * w;
+    const uint32_t *up = out + (uint64_t)(y0 ? y0 - 1 : 0) * w;  // thread 0 of a later band: the last row of the band before
+    const uint32_t *mrow = modes + (live ? (y >> bits) : 0u) * xf.xsize;
     uint32_t L = 0, T = 0, TL = 0;
-    const uint32_t rows_here = h - y0 < R ? h - y0 : R;
+    if (r == 0 && y0) T = up[0];
+    const uint32_t rows_here = h - y0 < kPredRows ? h - y0 : kPredRows;
     const uint32_t steps = w + 2 * (rows_here - 1);
+    // residuals (and, for thread 0, the row above) of the eight steps after the current eight
+    uint32_t nxt[8], upn[8];
+    auto fetch = [&](uint32_t t8) {  // for steps t8 .. t8 + 7
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) {
+        const int x = (int)(t8 + k) - 2 * (int)r;
+        nxt[k] = live && x >= 0 && x < (int)w ? row[x] : 0u;
+        upn[k] = r == 0 && y0 && t8 + k + 1 < w ? up[t8 + k + 1] : 0u;
+      }
+    };
+    fetch(0);
+    uint32_t mode = live ? (mrow[0] >> 8) & 0xff : 0u, mode_next = mode;
+    __syncthreads();  // the band before is done with the LDS arrays
     for (uint32_t t = 0; t < steps; t++) {
+      if ((t & 7u) == 0) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) ring[k][r] = nxt[k];
+        if (r == 0) {
+#pragma unroll
+          for (uint32_t k = 0; k < 8; k++) upring[k] = upn[k];
+        }
+        fetch(t + 8);  // a thread reads back only what it staged itself: no barrier
+      }
       const int x = (int)t - 2 * (int)r;
+      // what the thread above made one step ago: its pixel x + 1 (thread 0: the row above the band)
+      const uint32_t above = r ? hand[(t + 1) & 1u][r] : upring[t & 7u];
+      if (live && x == -1) T = above;  // pixel 0 of the row above
       if (live && x >= 0 && x < (int)w) {
         uint32_t P;
         if (y == 0) {
           P = x == 0 ? 0xff000000u : L;
+        } else if (x == 0) {
+          P = T;
+          TL = T;
+          T = above;
         } else {
-          if (x == 0) { T = up[0]; P = T; }
-          else {
-            const uint32_t TR = (x == (int)w - 1) ? L : up[x + 1];  // transform.h:137
-            const uint32_t mode = (modes[(y >> xf.bits) * xf.xsize + ((uint32_t)x >> xf.bits)] >> 8) & 0xff;
-            if (mode > 13) bad = true;
-            P = predict(mode, L, T, TR, TL);
-            TL = T;
-            T = TR;
-          }
-          if (x == 0) { TL = T; T = w > 1 ? up[1] : 0u; }
+          if (((uint32_t)x & tmask) == 0) mode = mode_next;
+          const uint32_t TR = (x == (int)w - 1) ? L : above;  // transform.h:137
+          if (mode > 13) bad = true;
+          P = predict(mode, L, T, TR, TL);
+          TL = T;
+          T = TR;
         }
-        L = px_add(row[x], P);
+        // the mode of the next tile, fetched when this one starts
+        if (((uint32_t)x & tmask) == 0 && (((uint32_t)x >> bits) + 1) < xf.xsize) mode_next = (mrow[((uint32_t)x >> bits) + 1] >> 8) & 0xff;
+        L = px_add(ring[t & 7u][r], P);
         row[x] = L;
+        hand[t & 1u][r + 1] = L;
       }
       __syncthreads();
     }
+    __threadfence_block();  // the next band's thread 0 reads this band's last row from HBM
   }
   if (bad) atomicExch(&res[img].status, (int32_t)kErrInvalidVp8l);
+}
+
+// The same inverse spread over the device: one CU runs out of instruction issue (the 14 modes diverge within a wave),
+// so an image is cut into bands of 64 rows, one wave each, that run as a pipeline: a band's first row needs the row
+// above it, which the band before publishes as it goes: that row's pixels and a progress counter are stored and read
+// past the caches (device-scope release/acquire would write back and invalidate whole L2s every few steps).  A band therefore trails the one before by about 140 steps.  Workgroups are
+// dispatched in index order and band b waits only for band b-1 of the same image, which has the lower index, so
+// the wait cannot deadlock; it is bounded all the same, and an image whose wait ran out is decoded again by the
+// one-workgroup kernel (status kPredRetry).
+constexpr uint32_t kBandRows = 64;
+constexpr int32_t kPredRetry = 4;  // DecResult.status value that is not a verdict
+__global__ __launch_bounds__(64) void k_inverse_predictor_bands(const DecImage *__restrict__ imgs, DecResult *__restrict__ res, uint32_t pass,
+                                                                uint32_t nimg, uint32_t max_bands, uint32_t *__restrict__ progress) {
+  __shared__ uint32_t ring[8][kBandRows];
+  // workgroups go round-robin to the 8 XCDs: the bands of an image stay on one XCD (one L2 between neighbours), eight
+  // images side by side; band b-1 of the image is workgroup blockIdx - 8
+  const uint32_t col = blockIdx.x % 8, j = blockIdx.x / 8, img = (j / max_bands) * 8 + col, band = j % max_bands, r = threadIdx.x;
+  if (img >= nimg) return;
+  XformRec xf;
+  if (!pass_transform(res[img], pass, xf) || xf.type != 0) return;
+  const DecImage im = imgs[img];
+  const uint32_t w = im.w, h = im.h, bits = xf.bits, tmask = (1u << bits) - 1u;
+  const uint32_t y0 = band * kBandRows;
+  if (y0 >= h) return;
+  const uint32_t *modes = im.aux + xf.data_off;
+  uint32_t *out = im.out;
+  uint32_t *mine = progress + (size_t)img * max_bands + band;            // pixels of this band's last row that are final
+  const uint32_t *theirs = band ? mine - 1 : nullptr;                    // the same of the band above
+  const uint32_t y = y0 + r;
+  const bool live = y < h;
+  uint32_t *row = out + (uint64_t)(live ? y : 0) * w;
+  const uint32_t *up = out + (uint64_t)(y0 ? y0 - 1 : 0) * w;
+  const uint32_t *mrow = modes + (live ? (y >> bits) : 0u) * xf.xsize;
+  const uint32_t rows_here = h - y0 < kBandRows ? h - y0 : kBandRows;
+  const uint32_t steps = w + 2 * (rows_here - 1);
+  bool bad = false, late = false;
+  // waits until the band above has finished `need` pixels of its last row
+  auto wait_for = [&](uint32_t need) {
+    if (!theirs || late) return;
+    need = need < w ? need : w;
+    for (uint32_t spin = 0;; spin++) {
+      // relaxed, past the caches: the row above is read the same way, so no cache has to be invalidated for it
+      const uint32_t have = uni(__hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (have >= need) return;
+      if (have == 0xffffffffu || spin > (1u << 22)) { late = true; return; }  // the band above gave up, or is not coming
+      __builtin_amdgcn_s_sleep(8);
+    }
+  };
+  uint32_t nxt[8], upn = 0;  // residuals of the eight steps after the current eight; lane k < 8 of upn: the row above for them
+  auto fetch = [&](uint32_t t8) {
+    wait_for(t8 + 9);
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      const int x = (int)(t8 + k) - 2 * (int)r;
+      nxt[k] = live && x >= 0 && x < (int)w ? row[x] : 0u;
+    }
+    upn = 0;
+    if (y0 && !late && r < 8 && t8 + r + 1 < w) upn = __hip_atomic_load(&up[t8 + r + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  uint32_t L = 0, T = 0, TL = 0, made = 0, upcur = 0;
+  if (y0) {
+    wait_for(1);
+    if (!late) T = __hip_atomic_load(&up[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // used by lane 0 only
+  }
+  fetch(0);
+  uint32_t mode = live ? (mrow[0] >> 8) & 0xff : 0u, mode_next = mode;
+  for (uint32_t t = 0; t < steps && !late; t++) {
+    if ((t & 7u) == 0) {
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) ring[k][r] = nxt[k];
+      upcur = upn;
+      // what the last row has finished so far goes out before the next fetch can wait on the band above
+      if (r == rows_here - 1) {
+        const int xdone = (int)t - 2 * (int)r;  // pixels 0 .. xdone-1 of this row are stored
+        if (xdone > 0) {
+          // the row's pixels were stored past the caches; once they have arrived (no cache write-back needed) the count follows
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __hip_atomic_store(mine, (uint32_t)xdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      fetch(t + 8);
+    }
+    const int x = (int)t - 2 * (int)r;
+    // what the lane above made one step ago: its pixel x + 1 (lane 0: the row above the band)
+    uint32_t above = (uint32_t)__shfl_up((int)made, 1, 64);
+    if (r == 0) above = lane_read(upcur, t & 7u);
+    if (live && x == -1) T = above;
+    if (live && x >= 0 && x < (int)w) {
+      uint32_t P;
+      if (y == 0) {
+        P = x == 0 ? 0xff000000u : L;
+      } else if (x == 0) {
+        P = T;
+        TL = T;
+        T = above;
+      } else {
+        if (((uint32_t)x & tmask) == 0) mode = mode_next;
+        const uint32_t TR = (x == (int)w - 1) ? L : above;  // transform.h:137
+        if (mode > 13) bad = true;
+        P = predict(mode, L, T, TR, TL);
+        TL = T;
+        T = TR;
+      }
+      if (((uint32_t)x & tmask) == 0 && (((uint32_t)x >> bits) + 1) < xf.xsize) mode_next = (mrow[((uint32_t)x >> bits) + 1] >> 8) & 0xff;
+      L = px_add(ring[t & 7u][r], P);
+      if (r == rows_here - 1) __hip_atomic_store(&row[x], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the band below reads this row
+      else row[x] = L;
+      made = L;
+    }
+  }
+  if (r == rows_here - 1) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(mine, late ? 0xffffffffu : w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (late) atomicExch(&res[img].status, kPredRetry);
+  else if (bad) atomicCAS(&res[img].status, (int32_t)kOk, (int32_t)kErrInvalidVp8l);
 }
 
 }  // namespace vp8l
@@ -1480,6 +1635,7 @@ struct vp8l_decoder {
   std::mutex mu;
   DeviceBuffer d_imgs, d_res, d_sbfirst, d_aux, d_scratch, d_groups, d_cache, d_sorted;
   DeviceBuffer d_par, d_srcg, d_segmap, d_segidx, d_segfirst, d_records;  // the segment kernels' workspace
+  DeviceBuffer d_progress;  // the banded predictor inverse: pixels finished per band
   double last_seconds = 0;
   int threads_per_stream = 0;  // 0: chosen per call
   int whole_device = 0;        // 0: chosen per call, 1: never, 2: whenever the stream qualifies
@@ -1523,7 +1679,7 @@ extern "C" void vp8l_decoder_destroy(vp8l_decoder *d) {
   if (d->ev0) (void)hipEventDestroy(d->ev0);
   if (d->ev1) (void)hipEventDestroy(d->ev1);
   DeviceBuffer *bufs[] = {&d->d_imgs, &d->d_res, &d->d_sbfirst, &d->d_aux, &d->d_scratch, &d->d_groups, &d->d_cache, &d->d_sorted,
-                          &d->d_par, &d->d_srcg, &d->d_segmap, &d->d_segidx, &d->d_segfirst, &d->d_records};
+                          &d->d_par, &d->d_srcg, &d->d_segmap, &d->d_segidx, &d->d_segfirst, &d->d_records, &d->d_progress};
   for (auto *b : bufs) b->release();
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
@@ -1533,7 +1689,7 @@ namespace {
 
 // One pass over the images listed in `idx` with `group_cap` multi-group table sets per image.
 int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t *const *d_data, const size_t *len,
-                const uint32_t *width, const uint32_t *height, uint32_t *const *d_argb, uint32_t group_cap, int whole_mode,
+                const uint32_t *width, const uint32_t *height, uint32_t *const *d_argb, uint32_t group_cap, int whole_mode, bool pred_bands,
                 std::vector<DecResult> &results) {
   const bool whole_device = whole_mode != 0;  // 1: scouts and records, 2: entry maps
   const uint32_t m = (uint32_t)idx.size();
@@ -1577,7 +1733,10 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
   }
   sb_first[m] = (uint32_t)sb_total;
   seg_first[m] = (uint32_t)seg_total;
+  uint32_t max_bands = 1;
+  for (uint32_t k = 0; k < m; k++) max_bands = std::max(max_bands, (height[idx[k]] + kBandRows - 1) / kBandRows);
   const bool ok = d->d_imgs.reserve(m * sizeof(DecImage)) && d->d_res.reserve(m * sizeof(DecResult)) &&
+                  d->d_progress.reserve((size_t)m * max_bands * 4) &&
                   d->d_sbfirst.reserve((m + 1) * 4) && d->d_aux.reserve(aux_total * 4) &&
                   d->d_scratch.reserve(scratch_total * 4) &&
                   d->d_groups.reserve((size_t)m * group_cap * sizeof(GroupTables) + 16) &&
@@ -1642,7 +1801,15 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
   for (uint32_t pass = 0; pass < 4; pass++) {
     hipLaunchKernelGGL(k_inverse_stash, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m, pass);
     hipLaunchKernelGGL(k_inverse_pointwise, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m, pass);
-    hipLaunchKernelGGL(k_inverse_predictor, dim3(m), dim3(1024), 0, s, dimgs, dres, pass);
+    if (pred_bands) {
+      (void)hipMemsetAsync(d->d_progress.ptr, 0, (size_t)m * max_bands * 4, s);
+      // 36 KiB of LDS nobody uses: at most four of these one-wave workgroups then share a CU (one per SIMD); left to
+      // itself the dispatcher packs dozens onto a few CUs and they take turns on the same SIMDs
+      hipLaunchKernelGGL(k_inverse_predictor_bands, dim3((m + 7) / 8 * 8 * max_bands), dim3(64), 36 << 10, s, dimgs, dres, pass, m, max_bands,
+                         d->d_progress.as<uint32_t>());
+    } else {
+      hipLaunchKernelGGL(k_inverse_predictor, dim3(m), dim3(kPredRows), 0, s, dimgs, dres, pass);
+    }
   }
   (void)hipEventRecord(d->ev1, s);
   if (!hip_ok(hipGetLastError(), "kernel launch")) return VP8L_ERR_HIP;
@@ -1687,21 +1854,24 @@ extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8
   // Passes: first everything (whole-device streams with scouts), then again what a pass handed on: streams whose
   // scouts were not in step (entry maps), streams the segment kernels cannot take (one workgroup), streams with more
   // Huffman groups than the pass provided.
-  struct Todo { std::vector<uint32_t> idx; int mode; uint32_t group_cap; };
+  struct Todo { std::vector<uint32_t> idx; int mode; uint32_t group_cap; bool pred_bands; };
   std::vector<Todo> todo;
-  todo.push_back({pending, whole_device ? 1 : 0, 4});
+  todo.push_back({pending, whole_device ? 1 : 0, 4, true});
   while (!todo.empty()) {
     Todo t = std::move(todo.back());
     todo.pop_back();
     std::vector<DecResult> results;
-    const int rc = decode_pass(d, t.idx, d_data, len, width, height, d_argb, t.group_cap, t.mode, results);
+    const int rc = decode_pass(d, t.idx, d_data, len, width, height, d_argb, t.group_cap, t.mode, t.pred_bands, results);
     if (rc != VP8L_OK) return rc;
-    Todo more_groups{{}, t.mode, t.group_cap}, with_maps{{}, 2, t.group_cap}, one_workgroup{{}, 0, t.group_cap};
+    Todo more_groups{{}, t.mode, t.group_cap, t.pred_bands}, with_maps{{}, 2, t.group_cap, t.pred_bands}, one_workgroup{{}, 0, t.group_cap, t.pred_bands},
+        one_block_predictor{{}, t.mode, t.group_cap, false};
     for (size_t k = 0; k < t.idx.size(); k++) {
       const DecResult &r = results[k];
       if (r.status == kErrWorkspace && r.need_groups > t.group_cap) {
         more_groups.idx.push_back(t.idx[k]);
         more_groups.group_cap = std::max(more_groups.group_cap, r.need_groups);
+      } else if (r.status == kPredRetry) {
+        one_block_predictor.idx.push_back(t.idx[k]);  // a band of the predictor inverse waited too long for the band above
       } else if (r.status == kParRetryMaps && t.mode == 1) {
         with_maps.idx.push_back(t.idx[k]);
       } else if (r.status == kParFallback || r.status == kParPending || r.status == kParRetryMaps) {
@@ -1711,7 +1881,7 @@ extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8
         if (t.mode && r.pad == 1) d->last_whole_device++;
       }
     }
-    for (Todo *n2 : {&more_groups, &with_maps, &one_workgroup})
+    for (Todo *n2 : {&more_groups, &with_maps, &one_workgroup, &one_block_predictor})
       if (!n2->idx.empty()) todo.push_back(std::move(*n2));
   }
   return VP8L_OK;
