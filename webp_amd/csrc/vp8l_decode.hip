@@ -792,7 +792,8 @@ constexpr uint32_t kParJumpPasses = 32;
 constexpr int32_t kParPending = 1, kParFallback = 2, kParRetryMaps = 3;  // DecResult.status values that are not verdicts
 constexpr uint32_t kParWarm = 4096;                   // stream bits a scout decodes before its segment to fall in step with the token chain
 constexpr uint32_t kParScoutWords = (kParSegBits + kParWarm) / 32 + 16;
-constexpr uint32_t kParRecCap = 8192;                  // token records per segment (8 bytes each: 8 times the segment's stream bytes)
+constexpr uint32_t kParRecCap = 16384;                 // token records per segment (8 bytes each: 16 times the segment's stream bytes);
+                                                       // a segment of 4-bit tokens fills them, shorter tokens send the stream to the entry maps
 constexpr uint32_t kFinalBit = 0x80000000u;             // in the per-pixel source array: this position holds its final value
 
 struct ParImage {
