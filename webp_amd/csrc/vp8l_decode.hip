@@ -906,7 +906,7 @@ __device__ __forceinline__ uint64_t par_setup(VP8L_LDS GroupTables &g, VP8L_LDS 
 }
 
 
-__global__ __launch_bounds__(kWgThreads) void k_par_maps(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ segfirst, uint32_t n) {
+__global__ __launch_bounds__(kWgThreads, 8) void k_par_maps(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ segfirst, uint32_t n) {
   __shared__ GroupTables g;
   __shared__ uint32_t win[kParWindowWords];
   __shared__ __attribute__((aligned(16))) WgShared sh;
@@ -992,7 +992,7 @@ __global__ __launch_bounds__(256) void k_par_chain(const DecImage *__restrict__ 
   }
 }
 
-__global__ __launch_bounds__(kWgThreads) void k_par_pixels(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ segfirst, uint32_t n) {
+__global__ __launch_bounds__(kWgThreads, 8) void k_par_pixels(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ segfirst, uint32_t n) {
   __shared__ GroupTables g_;
   __shared__ uint32_t win_[kParWindowWords];
   __shared__ __attribute__((aligned(16))) WgShared sh_;
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(kWgThreads) void k_par_pixels(const DecImage *__res
 // entered and left the segment; k_par_verify accepts the records only if every scout entered where its predecessor
 // left (segment 0 starts at the true position, so by induction all of them were on the true chain).  If one was not
 // (codes of one length never fall in step), the stream is decoded again with the entry maps of mode 2.
-__global__ __launch_bounds__(kWgThreads) void k_par_scout(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ segfirst, uint32_t n) {
+__global__ __launch_bounds__(kWgThreads, 8) void k_par_scout(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ segfirst, uint32_t n) {
   __shared__ GroupTables g_;
   __shared__ uint32_t win_[kParScoutWords];
   __shared__ __attribute__((aligned(16))) WgShared sh_;
@@ -1844,20 +1844,33 @@ extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8
     }
     pending.push_back((uint32_t)i);
   }
-  // The segment kernels (one stream spread over the device) pay when there are fewer streams than CUs and
-  // enough stream bytes to make segments for all of them: they decode about 2.7 GP/s of photo-like content
-  // whatever the number of streams, a workgroup per stream 17 MP/s times the number of streams (up to 256).
+  // The segment kernels (streams spread over the device) decode faster than a workgroup per stream for any number of
+  // streams (6.7 against 4.2 GP/s photo-like at 256 streams, 3 ms against 500 for one 4K stream); they need enough
+  // stream bytes to make segments worth launching, and 16 bytes of token records per stream byte, so a large batch
+  // goes through them in passes of at most 1 GiB of streams.
+  if (pending.empty()) return VP8L_OK;
   uint64_t stream_bytes = 0;
   for (uint32_t i : pending) stream_bytes += len[i];
-  bool whole_device = d->threads_per_stream != 64 &&
-                      (d->whole_device == 2 || (d->whole_device == 0 && pending.size() <= 128 && stream_bytes >= (2u << 20)));
+  const bool whole_device = d->threads_per_stream != 64 && (d->whole_device == 2 || (d->whole_device == 0 && stream_bytes >= (2u << 20)));
   d->last_whole_device = 0;
   // Passes: first everything (whole-device streams with scouts), then again what a pass handed on: streams whose
   // scouts were not in step (entry maps), streams the segment kernels cannot take (one workgroup), streams with more
   // Huffman groups than the pass provided.
   struct Todo { std::vector<uint32_t> idx; int mode; uint32_t group_cap; bool pred_bands; };
   std::vector<Todo> todo;
-  todo.push_back({pending, whole_device ? 1 : 0, 4, true});
+  if (whole_device) {
+    constexpr uint64_t kPassBytes = 1ull << 30;
+    std::vector<std::vector<uint32_t>> parts(1);
+    uint64_t acc = 0;
+    for (uint32_t i : pending) {
+      if (!parts.back().empty() && acc + len[i] > kPassBytes) { parts.emplace_back(); acc = 0; }
+      parts.back().push_back(i);
+      acc += len[i];
+    }
+    for (auto it = parts.rbegin(); it != parts.rend(); ++it) todo.push_back({std::move(*it), 1, 4, true});  // popped from the back
+  } else {
+    todo.push_back({pending, 0, 4, true});
+  }
   while (!todo.empty()) {
     Todo t = std::move(todo.back());
     todo.pop_back();
