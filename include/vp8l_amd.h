@@ -141,7 +141,11 @@ int vp8l_decoder_decode_device(vp8l_decoder *dec, size_t n, const uint8_t *const
  * several Huffman groups or tokens the segment decoder does not take are decoded by one workgroup each as before.
  * Workspace: 16 bytes per stream byte and 4 bytes per pixel, in passes of at most 1 GiB of streams.  Identical pixels
  * and verdicts. */
-enum { VP8L_DEC_OPT_THREADS_PER_STREAM = 1, VP8L_DEC_OPT_WHOLE_DEVICE = 2 };
+/* VP8L_DEC_OPT_SCOUT_FORM: how a segment's scout finds its tokens.  0 (default) = the segment is cut into pieces of 256
+ * bits, a lane decodes a piece token after token, first from a guessed entry and again from where the lane before it
+ * left, until no entry changes; 1 = a token is decoded at every bit offset and the chain is found by pointer jumping
+ * (the first version, several times slower).  Identical records, pixels and verdicts. */
+enum { VP8L_DEC_OPT_THREADS_PER_STREAM = 1, VP8L_DEC_OPT_WHOLE_DEVICE = 2, VP8L_DEC_OPT_SCOUT_FORM = 3 };
 int vp8l_decoder_set_option(vp8l_decoder *dec, int option, int value);
 /* Streams of the last call on the context that the segment kernels decoded. */
 long vp8l_decoder_last_whole_device_streams(const vp8l_decoder *dec);

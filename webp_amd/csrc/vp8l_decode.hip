@@ -398,9 +398,9 @@ struct WgShared {
 };
 
 __device__ __forceinline__ void wg_window_load(VP8L_LDS uint32_t *win, const DecImage &im, uint64_t lo, uint32_t tid,
-                                               uint32_t words = kWgWindowWords) {
+                                               uint32_t words = kWgWindowWords, uint32_t threads = kWgThreads) {
   const uint32_t *src = reinterpret_cast<const uint32_t *>(im.data);  // 4-byte aligned; bytes past the end read as zero
-  for (uint32_t i = tid; i < words; i += kWgThreads) {
+  for (uint32_t i = tid; i < words; i += threads) {
     const uint64_t pos = lo + 4ull * i;
     uint32_t v = 0;
     if (pos + 4 <= im.len) v = src[pos >> 2];
@@ -410,7 +410,8 @@ __device__ __forceinline__ void wg_window_load(VP8L_LDS uint32_t *win, const Dec
 }
 
 // One symbol at bit n of w (64 stream bits) by one thread; false when w does not hold all of it.
-__device__ __forceinline__ bool wg_sym(uint64_t w, uint32_t &n, const VP8L_LDS HuffTable &t, const VP8L_LDS WgShared &sh, uint32_t code,
+template <class Sh>
+__device__ __forceinline__ bool wg_sym(uint64_t w, uint32_t &n, const VP8L_LDS HuffTable &t, const VP8L_LDS Sh &sh, uint32_t code,
                                        uint32_t &sym) {
   if (n > 64 - kLutBits) return false;
   const uint32_t bits = (uint32_t)(w >> n);
@@ -435,8 +436,9 @@ __device__ __forceinline__ bool wg_sym(uint64_t w, uint32_t &n, const VP8L_LDS H
 }
 
 // What wg_sym needs for codes longer than the lookup table (a barrier must follow before the first use).
-__device__ __forceinline__ void wg_prepare_long(VP8L_LDS WgShared &sh, const VP8L_LDS GroupTables &g, uint32_t tid) {
-  for (uint32_t i = tid; i < kWgSorted; i += kWgThreads) sh.sorted[i] = g.sorted[i];
+template <class Sh>
+__device__ __forceinline__ void wg_prepare_long(VP8L_LDS Sh &sh, const VP8L_LDS GroupTables &g, uint32_t tid, uint32_t threads = kWgThreads) {
+  for (uint32_t i = tid; i < kWgSorted; i += threads) sh.sorted[i] = g.sorted[i];
   if (tid < kNumCodes * kWgLongSlots) {
     const uint32_t c = tid / kWgLongSlots, slot = tid % kWgLongSlots, l = kLutBits + 1 + slot;
     const VP8L_LDS HuffTable &t = g.t[c];
@@ -452,7 +454,8 @@ __device__ __forceinline__ void wg_prepare_long(VP8L_LDS WgShared &sh, const VP8
 
 // The token that starts at bit 0 of w: hop = its bits (0: not decodable from w alone), cnt = pixels it
 // makes, val = the pixel (literal) or the distance (ref).
-__device__ __forceinline__ void wg_token(uint64_t w, const VP8L_LDS GroupTables &g, const VP8L_LDS WgShared &sh, uint32_t xsize,
+template <class Sh>
+__device__ __forceinline__ void wg_token(uint64_t w, const VP8L_LDS GroupTables &g, const VP8L_LDS Sh &sh, uint32_t xsize,
                                          uint32_t &hop, uint32_t &cnt, uint32_t &val, bool &ref) {
   hop = 0; cnt = 0; val = 0; ref = false;
   uint32_t n = 0, S = 0;
@@ -1126,6 +1129,161 @@ __global__ __launch_bounds__(kWgThreads, 8) void k_par_scout(const DecImage *__r
   }
 }
 
+// ---- mode 1, lane form of the scouts.  k_par_scout finds the token chain of a span by decoding a token at every one
+// of its 1024 bit offsets; here a lane decodes tokens one after another, as a serial decoder would.  The stream is cut
+// into pieces of kLaneBits bits, one per lane (a segment is kLanesPerSeg pieces, a workgroup takes kLaneThreads pieces
+// of one stream and keeps its code tables in LDS; the stream bits come straight from memory, 8 bytes at a time, two
+// words ahead of their use).  Every lane first decodes its piece from the piece's first bit (a guess), then again
+// from where the lane before it really left its piece, until no lane's entry changes.  The entry of a workgroup's
+// first lane is fixed (it falls in step over the piece before it, as k_par_scout does over kParWarm bits), so after
+// pass k the first k lanes are final, and because a Huffman-coded stream falls in step by itself - within a piece,
+// nearly always - two passes settle nearly all lanes.  A last pass writes the token records.  The stream bits are
+// decoded about three times instead of 64 times.  What the kernel leaves behind (records, entry, exit, counts,
+// flags per segment) is what k_par_scout leaves, so k_par_verify and k_par_place follow.
+constexpr uint32_t kLaneBits = 8192;
+constexpr uint32_t kLanesPerSeg = kParSegBits / kLaneBits;
+constexpr uint32_t kLaneThreads = 256;
+constexpr uint32_t kLaneSegsPerWg = kLaneThreads / kLanesPerSeg;
+constexpr uint32_t kLanePasses = 8;   // entries still changing after this many passes: the stream does not fall in step
+static_assert(kLaneBits < kParSegBits && (kLanesPerSeg & (kLanesPerSeg - 1)) == 0 && kLanesPerSeg <= 64, "the lanes of a segment sit in one wave");
+static_assert(kLaneThreads % 64 == 0 && kLaneThreads >= kNumCodes * kWgLongSlots, "whole waves; one thread per long-code slot");
+
+struct LaneShared {
+  uint32_t lim[kNumCodes][kWgLongSlots];   // as in WgShared
+  uint32_t base[kNumCodes][kWgLongSlots];
+  uint16_t sorted[kWgSorted];
+  uint8_t exit_off[kLaneThreads];          // where the chain of lane j enters piece j + 1 (0..63), or kParStop
+};
+
+// A lane's view of the stream: 64 bits from any bit position, moving forward by at most 64 bits at a time.
+struct LaneBits {
+  const uint64_t *base;  // the stream's first byte rounded down to 8 bytes
+  uint64_t nbytes;       // bytes from `base` to the stream's end; bytes beyond read as zero
+  uint64_t A, B, C;      // words k, k + 1, k + 2
+  uint32_t k, s;         // the position is bit s of word k
+  __device__ __forceinline__ uint64_t word(uint32_t i) const {
+    const uint64_t at = 8ull * i;
+    if (at >= nbytes) return 0;
+    const uint64_t v = base[i];  // an aligned word that holds a byte of the stream: readable to its end
+    return at + 8 <= nbytes ? v : v & (~0ull >> (8 * (8 - (uint32_t)(nbytes - at))));
+  }
+  __device__ __forceinline__ void seek(uint64_t bit) {
+    k = (uint32_t)(bit >> 6); s = (uint32_t)bit & 63u;
+    A = word(k); B = word(k + 1); C = word(k + 2);
+  }
+  __device__ __forceinline__ uint64_t peek() const { return s ? (A >> s) | (B << (64 - s)) : A; }
+  __device__ __forceinline__ void skip(uint32_t n) {
+    s += n;
+    if (s >= 64) { s -= 64; k++; A = B; B = C; C = word(k + 2); }
+  }
+};
+
+// Tokens from bit `rel` of the piece (negative: the warm-up before it) until one starts at or after bit `end`; returns
+// how far beyond.  kRecord: their records go to rec[0..cap).
+template <bool kRecord>
+__device__ __forceinline__ uint32_t lane_run(LaneBits &lb, uint64_t piece_bit, int32_t rel, int32_t end, const VP8L_LDS GroupTables &g,
+                                             const VP8L_LDS LaneShared &sh, uint32_t xsize, bool warm, uint64_t *rec, uint32_t cap,
+                                             uint32_t &ntok, uint32_t &npx) {
+  ntok = 0; npx = 0;
+  lb.seek(piece_bit + (int64_t)rel);
+  while (rel < end) {
+    uint32_t hop, cnt, val;
+    bool ref;
+    wg_token(lb.peek(), g, sh, xsize, hop, cnt, val, ref);
+    if (hop == 0) {
+      if (!warm) return kParStop;  // a token this decoder cannot take
+      hop = 1;                     // warm-up: this need not be a token start, try the next bit
+    } else {
+      if (kRecord && ntok < cap) rec[ntok] = (uint64_t)val | ((uint64_t)cnt << 32) | ((uint64_t)(ref ? 1u : 0u) << 40);
+      ntok++;
+      npx += cnt;
+    }
+    lb.skip(hop);
+    rel += (int32_t)hop;
+  }
+  return (uint32_t)(rel - end);
+}
+
+__global__ __launch_bounds__(kLaneThreads) void k_par_scout_lanes(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ wgfirst, uint32_t n) {
+  __shared__ GroupTables g_;
+  __shared__ __attribute__((aligned(16))) LaneShared sh_;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t img = find_image(wgfirst, n, blockIdx.x), wg = blockIdx.x - wgfirst[img];
+  const DecImage im = imgs[img];
+  ParImage *par = im.par;
+  if (!par || !par->active || par->mode != 1 || wg * kLaneSegsPerWg >= par->nseg) return;
+  VP8L_LDS GroupTables &g = (VP8L_LDS GroupTables &)g_;
+  VP8L_LDS LaneShared &sh = (VP8L_LDS LaneShared &)sh_;
+  for (uint32_t i = tid; i < sizeof(GroupTables) / 4; i += kLaneThreads)
+    reinterpret_cast<VP8L_LDS uint32_t *>(&g)[i] = reinterpret_cast<const uint32_t *>(&par->tables)[i];
+  __syncthreads();
+  wg_prepare_long(sh, g, tid, kLaneThreads);
+  __syncthreads();
+  const uint32_t xsize = par->xsize;
+  const uint32_t seg = wg * kLaneSegsPerWg + tid / kLanesPerSeg;   // this lane's segment
+  const uint64_t q = (uint64_t)wg * kLaneThreads + tid;             // this lane's piece of the stream
+  // Pieces that start beyond the stream's last byte hold no token of a complete stream (and zeros never fall in step:
+  // they repeat one token); a stream that ends before its image does gets its verdict from the one-workgroup form.
+  const bool live = seg < par->nseg, active = live && par->P0 + q * kLaneBits < 8ull * im.len;
+  LaneBits lb;
+  {
+    const uintptr_t at = reinterpret_cast<uintptr_t>(im.data), down = at & 7u;  // the stream is 4-byte aligned
+    lb.base = reinterpret_cast<const uint64_t *>(at - down);
+    lb.nbytes = im.len + down;
+  }
+  const uint64_t piece_bit = par->P0 + q * kLaneBits + 8 * (reinterpret_cast<uintptr_t>(im.data) & 7u);
+  uint32_t in = 0, done_in = 0xffffffffu, out = 0, ntok = 0, npx = 0;
+  // the first lane falls in step over the piece before its own (the stream's first piece starts at the first token)
+  if (tid == 0 && q > 0 && active) in = lane_run<false>(lb, piece_bit, -(int32_t)kLaneBits, 0, g, sh, xsize, true, nullptr, 0, ntok, npx);
+  bool settled = false;
+  for (uint32_t pass = 0; pass < kLanePasses; pass++) {
+    const bool redo = active && in != done_in && in != kParStop;
+    if (!__syncthreads_or(redo)) { settled = true; break; }
+    if (redo) {
+      out = lane_run<false>(lb, piece_bit, (int32_t)in, (int32_t)kLaneBits, g, sh, xsize, false, nullptr, 0, ntok, npx);
+      done_in = in;
+      sh.exit_off[tid] = (uint8_t)out;
+    }
+    __syncthreads();
+    if (tid > 0 && active) in = sh.exit_off[tid - 1];
+  }
+  // per segment (kLanesPerSeg neighbouring lanes): the first lane that met a token it cannot take ends the records
+  const uint32_t sub = lane & (kLanesPerSeg - 1);
+  uint32_t stop = active && (in == kParStop || out == kParStop) ? sub : kLanesPerSeg;
+#pragma unroll
+  for (uint32_t o = 1; o < kLanesPerSeg; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_xor((int)stop, (int)o, 64);
+    stop = t < stop ? t : stop;
+  }
+  if (!active || sub > stop || in == kParStop) { ntok = 0; npx = 0; }
+  uint32_t itok = ntok, all_px = npx;
+#pragma unroll
+  for (uint32_t o = 1; o < kLanesPerSeg; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)itok, o, 64);
+    if (sub >= o) itok += t;
+    all_px += (uint32_t)__shfl_xor((int)all_px, (int)o, 64);
+  }
+  const uint32_t all_tok = (uint32_t)__shfl((int)itok, (int)(lane | (kLanesPerSeg - 1)), 64);
+  uint32_t flags = 0;
+  if (!settled) flags |= 2;                 // not in step: the entry maps decode this stream
+  if (all_tok > kParRecCap) flags |= 2;     // more tokens than records
+  if (stop < kLanesPerSeg) flags |= 1;      // the stream goes to the one-workgroup form if the image is not complete by then
+  if (!(flags & 2) && ntok) {
+    const uint32_t off = itok - ntok;
+    uint32_t t2, p2;
+    (void)lane_run<true>(lb, piece_bit, (int32_t)in, (int32_t)kLaneBits, g, sh, xsize, false, par->records + (size_t)seg * kParRecCap + off,
+                         kParRecCap - off, t2, p2);
+  }
+  if (live) {
+    uint64_t *slot = par->segmap + (size_t)seg * 64;
+    if (sub == kLanesPerSeg - 1) {
+      slot[0] = (uint64_t)(stop < kLanesPerSeg ? 0u : out) | ((uint64_t)all_px << 32);
+      slot[2] = flags;
+    }
+    if (sub == 0) slot[1] = (uint64_t)(in == kParStop ? 0u : in) | ((uint64_t)all_tok << 32);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_par_verify(const DecImage *__restrict__ imgs) {
   constexpr uint32_t kChunk = 256;
   __shared__ uint64_t s0[kChunk], s1[kChunk], s2[kChunk];
@@ -1635,12 +1793,13 @@ struct vp8l_decoder {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
   DeviceBuffer d_imgs, d_res, d_sbfirst, d_aux, d_scratch, d_groups, d_cache, d_sorted;
-  DeviceBuffer d_par, d_srcg, d_segmap, d_segidx, d_segfirst, d_records;  // the segment kernels' workspace
+  DeviceBuffer d_par, d_srcg, d_segmap, d_segidx, d_segfirst, d_lanefirst, d_records;  // the segment kernels' workspace
   DeviceBuffer d_progress;  // the banded predictor inverse: pixels finished per band
   double last_seconds = 0;
   int threads_per_stream = 0;  // 0: chosen per call
   int whole_device = 0;        // 0: chosen per call, 1: never, 2: whenever the stream qualifies
   uint32_t last_whole_device = 0;  // streams of the last call that the segment kernels decoded
+  int scout_form = 0;          // 0: a lane per piece of a segment (k_par_scout_lanes), 1: a token at every bit offset (k_par_scout)
 };
 
 extern "C" int vp8l_decoder_set_option(vp8l_decoder *d, int option, int value) {
@@ -1652,6 +1811,10 @@ extern "C" int vp8l_decoder_set_option(vp8l_decoder *d, int option, int value) {
   }
   if (option == VP8L_DEC_OPT_WHOLE_DEVICE && value >= 0 && value <= 2) {
     d->whole_device = value;
+    return VP8L_OK;
+  }
+  if (option == VP8L_DEC_OPT_SCOUT_FORM && (value == 0 || value == 1)) {
+    d->scout_form = value;
     return VP8L_OK;
   }
   return VP8L_ERR_BAD_ARGUMENT;
@@ -1680,7 +1843,7 @@ extern "C" void vp8l_decoder_destroy(vp8l_decoder *d) {
   if (d->ev0) (void)hipEventDestroy(d->ev0);
   if (d->ev1) (void)hipEventDestroy(d->ev1);
   DeviceBuffer *bufs[] = {&d->d_imgs, &d->d_res, &d->d_sbfirst, &d->d_aux, &d->d_scratch, &d->d_groups, &d->d_cache, &d->d_sorted,
-                          &d->d_par, &d->d_srcg, &d->d_segmap, &d->d_segidx, &d->d_segfirst, &d->d_records, &d->d_progress};
+                          &d->d_par, &d->d_srcg, &d->d_segmap, &d->d_segidx, &d->d_segfirst, &d->d_lanefirst, &d->d_records, &d->d_progress};
   for (auto *b : bufs) b->release();
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
@@ -1695,7 +1858,7 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
   const bool whole_device = whole_mode != 0;  // 1: scouts and records, 2: entry maps
   const uint32_t m = (uint32_t)idx.size();
   std::vector<DecImage> imgs(m);
-  std::vector<uint32_t> sb_first(m + 1, 0), seg_first(m + 1, 0);
+  std::vector<uint32_t> sb_first(m + 1, 0), seg_first(m + 1, 0), lane_first(m + 1, 0);
   std::vector<ParImage> pars(whole_device ? m : 0);
   uint64_t aux_total = 0, scratch_total = 0, sb_total = 0, px_total = 0, seg_total = 0;
   for (uint32_t k = 0; k < m; k++) {
@@ -1727,6 +1890,7 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
       pars[k].segmap = reinterpret_cast<uint64_t *>(seg_total * 64);
       pars[k].segentry = reinterpret_cast<uint32_t *>((seg_total + k) * 2);
       seg_first[k] = (uint32_t)seg_total;
+      lane_first[k + 1] = lane_first[k] + (uint32_t)((nseg + kLaneSegsPerWg - 1) / kLaneSegsPerWg);
       px_total += ((uint64_t)w * h + 63) & ~63ull;
       seg_total += nseg;
       if (seg_total > 0x3fffffffu) return VP8L_ERR_NO_MEMORY;
@@ -1746,7 +1910,7 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
   if (!ok) return VP8L_ERR_NO_MEMORY;
   if (whole_device) {
     if (!d->d_par.reserve(m * sizeof(ParImage)) || !d->d_srcg.reserve(px_total * 4) || !d->d_segmap.reserve(seg_total * 64 * 8) ||
-        !d->d_segidx.reserve((seg_total + m) * 2 * 4) || !d->d_segfirst.reserve((m + 1) * 4) ||
+        !d->d_segidx.reserve((seg_total + m) * 2 * 4) || !d->d_segfirst.reserve((m + 1) * 4) || !d->d_lanefirst.reserve((m + 1) * 4) ||
         (whole_mode == 1 && !d->d_records.reserve(seg_total * kParRecCap * 8)))
       return VP8L_ERR_NO_MEMORY;
     for (uint32_t k = 0; k < m; k++) {
@@ -1775,7 +1939,8 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
     return VP8L_ERR_HIP;
   if (whole_device &&
       (!hip_ok(hipMemcpyAsync(d->d_par.ptr, pars.data(), m * sizeof(ParImage), hipMemcpyHostToDevice, s), "upload segment workspace") ||
-       !hip_ok(hipMemcpyAsync(d->d_segfirst.ptr, seg_first.data(), (m + 1) * 4, hipMemcpyHostToDevice, s), "upload segment table")))
+       !hip_ok(hipMemcpyAsync(d->d_segfirst.ptr, seg_first.data(), (m + 1) * 4, hipMemcpyHostToDevice, s), "upload segment table") ||
+       !hip_ok(hipMemcpyAsync(d->d_lanefirst.ptr, lane_first.data(), (m + 1) * 4, hipMemcpyHostToDevice, s), "upload piece table")))
     return VP8L_ERR_HIP;
   const uint32_t gunits = (uint32_t)(sb_total * kUnitsPerSuper);
   (void)hipEventRecord(d->ev0, s);
@@ -1787,7 +1952,8 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
     // streams whose main image k_decode_entropy_wg left to the segment kernels (the others are finished: these kernels pass them by)
     const uint32_t *segf = d->d_segfirst.as<uint32_t>();
     if (whole_mode == 1) {
-      hipLaunchKernelGGL(k_par_scout, dim3((uint32_t)seg_total), dim3(kWgThreads), 0, s, dimgs, segf, m);
+      if (d->scout_form == 1) hipLaunchKernelGGL(k_par_scout, dim3((uint32_t)seg_total), dim3(kWgThreads), 0, s, dimgs, segf, m);
+      else hipLaunchKernelGGL(k_par_scout_lanes, dim3(lane_first[m]), dim3(kLaneThreads), 0, s, dimgs, d->d_lanefirst.as<uint32_t>(), m);
       hipLaunchKernelGGL(k_par_verify, dim3(m), dim3(256), 0, s, dimgs);
       hipLaunchKernelGGL(k_par_place, dim3((uint32_t)seg_total), dim3(kWgThreads), 0, s, dimgs, segf, m);
     } else {
