@@ -419,6 +419,7 @@ __device__ __forceinline__ bool wg_sym(uint64_t w, uint32_t &n, const VP8L_LDS H
   if (e != kLongCode) { n += e & 15u; sym = e >> 4; return true; }
   // A canonical code read as a left-justified number grows with its length, so the length is 11 + the number
   // of lengths whose largest value is still below the stream's: a few independent reads instead of a walk.
+  asm volatile("" ::: "memory");  // a caller's token loop must not load the limits of every code ahead of the loop, into a hundred registers
   const uint32_t v = __brev(bits);
   uint32_t slot = 0;
   for (uint32_t s0 = 0; s0 < kWgLongSlots; s0 += kWgLongBatch) {
@@ -454,7 +455,7 @@ __device__ __forceinline__ void wg_prepare_long(VP8L_LDS Sh &sh, const VP8L_LDS 
 
 // The token that starts at bit 0 of w: hop = its bits (0: not decodable from w alone), cnt = pixels it
 // makes, val = the pixel (literal) or the distance (ref).
-template <class Sh>
+template <bool kValue = true, class Sh>
 __device__ __forceinline__ void wg_token(uint64_t w, const VP8L_LDS GroupTables &g, const VP8L_LDS Sh &sh, uint32_t xsize,
                                          uint32_t &hop, uint32_t &cnt, uint32_t &val, bool &ref) {
   hop = 0; cnt = 0; val = 0; ref = false;
@@ -463,7 +464,7 @@ __device__ __forceinline__ void wg_token(uint64_t w, const VP8L_LDS GroupTables 
   if (S < 256) {
     uint32_t r = 0, b = 0, a = 0;
     if (!wg_sym(w, n, g.t[kRed], sh, kRed, r) || !wg_sym(w, n, g.t[kBlue], sh, kBlue, b) || !wg_sym(w, n, g.t[kAlpha], sh, kAlpha, a)) return;
-    val = (a << 24) | (r << 16) | (S << 8) | b;
+    if (kValue) val = (a << 24) | (r << 16) | (S << 8) | b;
     cnt = 1;
     hop = n;
   } else if (S < 280) {
@@ -479,7 +480,7 @@ __device__ __forceinline__ void wg_token(uint64_t w, const VP8L_LDS GroupTables 
     const uint32_t dcode = base + (nb ? (uint32_t)(w >> n) & ((1u << nb) - 1u) : 0u);
     n += nb;
     if (length > kWgMaxLen) return;
-    val = code_to_dist(xsize, dcode);
+    if (kValue) val = code_to_dist(xsize, dcode);  // else only the token's bits and pixels are wanted
     cnt = length;
     ref = true;
     hop = n;
@@ -791,7 +792,7 @@ constexpr uint32_t kParSegBits = kParSpans * kWgSpan;
 constexpr uint32_t kParWindowWords = kParSegBits / 32 + 16;
 constexpr uint32_t kParStop = 0x7f, kParNone = 0xff;   // exit codes next to the bit offsets 0..63
 constexpr uint32_t kParMinPixels = 1u << 16;            // smaller images are not worth the extra passes
-constexpr uint32_t kParJumpPasses = 32;
+constexpr uint32_t kParJumpPasses = 16;                  // a pass makes every open chain at least four times shorter
 constexpr int32_t kParPending = 1, kParFallback = 2, kParRetryMaps = 3;  // DecResult.status values that are not verdicts
 constexpr uint32_t kParWarm = 4096;                   // stream bits a scout decodes before its segment to fall in step with the token chain
 constexpr uint32_t kParScoutWords = (kParSegBits + kParWarm) / 32 + 16;
@@ -1131,80 +1132,125 @@ __global__ __launch_bounds__(kWgThreads, 8) void k_par_scout(const DecImage *__r
 
 // ---- mode 1, lane form of the scouts.  k_par_scout finds the token chain of a span by decoding a token at every one
 // of its 1024 bit offsets; here a lane decodes tokens one after another, as a serial decoder would.  The stream is cut
-// into pieces of kLaneBits bits, one per lane (a segment is kLanesPerSeg pieces, a workgroup takes kLaneThreads pieces
-// of one stream and keeps its code tables in LDS; the stream bits come straight from memory, 8 bytes at a time, two
-// words ahead of their use).  Every lane first decodes its piece from the piece's first bit (a guess), then again
-// from where the lane before it really left its piece, until no lane's entry changes.  The entry of a workgroup's
-// first lane is fixed (it falls in step over the piece before it, as k_par_scout does over kParWarm bits), so after
-// pass k the first k lanes are final, and because a Huffman-coded stream falls in step by itself - within a piece,
-// nearly always - two passes settle nearly all lanes.  A last pass writes the token records.  The stream bits are
-// decoded about three times instead of 64 times.  What the kernel leaves behind (records, entry, exit, counts,
-// flags per segment) is what k_par_scout leaves, so k_par_verify and k_par_place follow.
+// into pieces of kLaneBits bits, one per lane; a segment is kLanesPerSeg pieces, a workgroup takes kLaneSegsPerWg
+// segments of one stream (and the piece before them: warm-up) and keeps the stream's code tables in LDS.  Every lane
+// first decodes its piece from the piece's first bit (a guess), then again from where the lane before it really left
+// its piece, until no lane's entry changes.  The warm-up lane's entry stays a guess (it falls in step over its piece,
+// as k_par_scout does over kParWarm bits; the stream's first piece starts at the first token), so after pass k the
+// first k lanes are final, and because a Huffman-coded stream falls in step by itself - within a piece, nearly
+// always - two or three passes settle all lanes.  A last pass writes the token records.  The stream bits are decoded
+// about four times instead of 64 times.
+// Lanes that each walk through their own kilobyte of the stream would fetch a cache line per 8 bytes they use, and
+// with 2048 lanes on a CU no cache keeps those lines until their next use (measured: 4.4 times slower than this).
+// So the lanes move in rounds of kLaneChunkBits bits: the workgroup loads the next 64 bytes of every lane's piece
+// with whole-line reads into registers while the lanes decode, and puts them into a ring in LDS at the round's end.
+// What the kernel leaves behind (records, entry, exit, counts, flags per segment) is what k_par_scout leaves, so
+// k_par_verify and k_par_place follow.
 constexpr uint32_t kLaneBits = 8192;
 constexpr uint32_t kLanesPerSeg = kParSegBits / kLaneBits;
 constexpr uint32_t kLaneThreads = 256;
-constexpr uint32_t kLaneSegsPerWg = kLaneThreads / kLanesPerSeg;
+constexpr uint32_t kLaneSegsPerWg = kLaneThreads / kLanesPerSeg - 1;  // the last lane of the first group has the warm-up piece
+constexpr uint32_t kLaneChunkWords = 4;                               // 64-bit words of every piece loaded at a time
+constexpr uint32_t kLaneChunkBits = 64 * kLaneChunkWords;
+constexpr uint32_t kLaneRounds = kLaneBits / kLaneChunkBits;
+constexpr uint32_t kLaneRing = 2 * kLaneChunkWords;                   // the chunk being decoded and the one after it
+constexpr uint32_t kLaneRingStride = kLaneThreads + 1;                // words of one lane in different banks
 constexpr uint32_t kLanePasses = 8;   // entries still changing after this many passes: the stream does not fall in step
 static_assert(kLaneBits < kParSegBits && (kLanesPerSeg & (kLanesPerSeg - 1)) == 0 && kLanesPerSeg <= 64, "the lanes of a segment sit in one wave");
 static_assert(kLaneThreads % 64 == 0 && kLaneThreads >= kNumCodes * kWgLongSlots, "whole waves; one thread per long-code slot");
+static_assert(64 % kLaneChunkWords == 0 && kLaneBits % kLaneChunkBits == 0 && kLaneBits % 64 == 0, "chunks");
 
 struct LaneShared {
   uint32_t lim[kNumCodes][kWgLongSlots];   // as in WgShared
   uint32_t base[kNumCodes][kWgLongSlots];
   uint16_t sorted[kWgSorted];
   uint8_t exit_off[kLaneThreads];          // where the chain of lane j enters piece j + 1 (0..63), or kParStop
+  uint64_t ring[kLaneRing][kLaneRingStride];  // [word of the piece mod kLaneRing][lane]
 };
 
-// A lane's view of the stream: 64 bits from any bit position, moving forward by at most 64 bits at a time.
-struct LaneBits {
-  const uint64_t *base;  // the stream's first byte rounded down to 8 bytes
-  uint64_t nbytes;       // bytes from `base` to the stream's end; bytes beyond read as zero
-  uint64_t A, B, C;      // words k, k + 1, k + 2
-  uint32_t k, s;         // the position is bit s of word k
-  __device__ __forceinline__ uint64_t word(uint32_t i) const {
-    const uint64_t at = 8ull * i;
-    if (at >= nbytes) return 0;
+// The stream as 64-bit words from its first byte rounded down to 8 bytes; bytes beyond its end read as zero.
+struct LaneStream {
+  const uint64_t *base;
+  uint64_t nbytes;   // from `base` to the stream's end
+  int64_t word0;     // the workgroup's lane 0 would start in this word (lanes below the warm-up lane do not exist)
+  __device__ __forceinline__ uint64_t word(int64_t i) const {
+    const uint64_t at = 8ull * (uint64_t)i;
+    if (i < 0 || at >= nbytes) return 0;
     const uint64_t v = base[i];  // an aligned word that holds a byte of the stream: readable to its end
     return at + 8 <= nbytes ? v : v & (~0ull >> (8 * (8 - (uint32_t)(nbytes - at))));
   }
-  __device__ __forceinline__ void seek(uint64_t bit) {
-    k = (uint32_t)(bit >> 6); s = (uint32_t)bit & 63u;
-    A = word(k); B = word(k + 1); C = word(k + 2);
+  // chunk c of the pieces of the 64 lanes of a wave, loaded by that wave: kLaneChunkWords neighbouring threads per lane
+  __device__ __forceinline__ void load(uint32_t c, uint32_t tid, uint64_t (&regs)[kLaneChunkWords]) const {
+#pragma unroll
+    for (uint32_t i = 0; i < kLaneChunkWords; i++) {
+      const uint32_t l = (tid & ~63u) + (tid & 63u) / kLaneChunkWords + i * (64 / kLaneChunkWords), w = tid % kLaneChunkWords;
+      regs[i] = word(word0 + (int64_t)l * (kLaneBits / 64) + c * kLaneChunkWords + w);
+    }
   }
-  __device__ __forceinline__ uint64_t peek() const { return s ? (A >> s) | (B << (64 - s)) : A; }
-  __device__ __forceinline__ void skip(uint32_t n) {
-    s += n;
-    if (s >= 64) { s -= 64; k++; A = B; B = C; C = word(k + 2); }
+  __device__ __forceinline__ void store(uint32_t c, uint32_t tid, const uint64_t (&regs)[kLaneChunkWords], VP8L_LDS LaneShared &sh) const {
+#pragma unroll
+    for (uint32_t i = 0; i < kLaneChunkWords; i++) {
+      const uint32_t l = (tid & ~63u) + (tid & 63u) / kLaneChunkWords + i * (64 / kLaneChunkWords), w = tid % kLaneChunkWords;
+      sh.ring[(c * kLaneChunkWords + w) % kLaneRing][l] = regs[i];
+    }
   }
 };
 
-// Tokens from bit `rel` of the piece (negative: the warm-up before it) until one starts at or after bit `end`; returns
-// how far beyond.  kRecord: their records go to rec[0..cap).
-template <bool kRecord>
-__device__ __forceinline__ uint32_t lane_run(LaneBits &lb, uint64_t piece_bit, int32_t rel, int32_t end, const VP8L_LDS GroupTables &g,
-                                             const VP8L_LDS LaneShared &sh, uint32_t xsize, bool warm, uint64_t *rec, uint32_t cap,
-                                             uint32_t &ntok, uint32_t &npx) {
-  ntok = 0; npx = 0;
-  lb.seek(piece_bit + (int64_t)rel);
-  while (rel < end) {
-    uint32_t hop, cnt, val;
-    bool ref;
-    wg_token(lb.peek(), g, sh, xsize, hop, cnt, val, ref);
-    if (hop == 0) {
-      if (!warm) return kParStop;  // a token this decoder cannot take
-      hop = 1;                     // warm-up: this need not be a token start, try the next bit
-    } else {
-      if (kRecord && ntok < cap) rec[ntok] = (uint64_t)val | ((uint64_t)cnt << 32) | ((uint64_t)(ref ? 1u : 0u) << 40);
-      ntok++;
-      npx += cnt;
-    }
-    lb.skip(hop);
-    rel += (int32_t)hop;
-  }
-  return (uint32_t)(rel - end);
+// A wave's part of the ring is written and read by that wave alone: its LDS operations complete in order, the
+// compiler must keep them in order too.
+__device__ __forceinline__ void lane_ring_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(kLaneThreads) void k_par_scout_lanes(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ wgfirst, uint32_t n) {
+// One pass of the whole workgroup over its pieces; every thread calls it (the waves do not wait for each other).  A lane with `run` decodes the tokens
+// from bit `in` of its piece until one starts in the next piece (`out`: how far in), or until it meets a token it
+// cannot take (out = kParStop; a warm-up lane moves on by a bit instead).  kRecord: the records go to rec[0..cap).
+template <bool kRecord>
+__device__ __forceinline__ void lanes_pass(const LaneStream &ls, uint32_t s0, bool run, bool warm, uint32_t in, const VP8L_LDS GroupTables &g,
+                                           VP8L_LDS LaneShared &sh, uint32_t xsize, uint32_t tid, uint64_t *rec, uint32_t cap,
+                                           uint32_t &out, uint32_t &ntok, uint32_t &npx) {
+  uint64_t regs[kLaneChunkWords];
+  ls.load(0, tid, regs);
+  ls.store(0, tid, regs, sh);
+  ls.load(1, tid, regs);
+  ls.store(1, tid, regs, sh);
+  lane_ring_sync();
+  uint32_t rel = in, k = (s0 + in) >> 6, s = (s0 + in) & 63u, tok = 0, px = 0;
+  uint64_t A = sh.ring[k % kLaneRing][tid], B = sh.ring[(k + 1) % kLaneRing][tid], C = sh.ring[(k + 2) % kLaneRing][tid];
+  bool stopped = false;
+#pragma unroll 1
+  for (uint32_t r = 0; r < kLaneRounds; r++) {
+    const bool more = r + 2 <= kLaneRounds;   // the last round reads into the first chunk of the next piece
+    if (more) ls.load(r + 2, tid, regs);
+    if (run && !stopped) {
+      const uint32_t lim = (r + 1) * kLaneChunkBits;
+      while (rel < lim) {
+        uint32_t hop, cnt, val;
+        bool ref;
+        wg_token<kRecord>(s ? (A >> s) | (B << (64 - s)) : A, g, sh, xsize, hop, cnt, val, ref);
+        if (hop == 0) {
+          if (!warm) { stopped = true; break; }
+          hop = 1;  // this need not be a token start, try the next bit
+        } else {
+          if (kRecord && tok < cap) rec[tok] = (uint64_t)val | ((uint64_t)cnt << 32) | ((uint64_t)(ref ? 1u : 0u) << 40);
+          tok++;
+          px += cnt;
+        }
+        rel += hop;
+        s += hop;
+        if (s >= 64) { s -= 64; k++; A = B; B = C; C = sh.ring[(k + 2) % kLaneRing][tid]; }
+      }
+    }
+    lane_ring_sync();
+    if (more) ls.store(r + 2, tid, regs, sh);
+    lane_ring_sync();
+  }
+  if (run) { out = stopped ? kParStop : rel - kLaneBits; ntok = tok; npx = px; }
+}
+
+__global__ __launch_bounds__(kLaneThreads, 5) void k_par_scout_lanes(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ wgfirst, uint32_t n) {
   __shared__ GroupTables g_;
   __shared__ __attribute__((aligned(16))) LaneShared sh_;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -1220,42 +1266,44 @@ __global__ __launch_bounds__(kLaneThreads) void k_par_scout_lanes(const DecImage
   wg_prepare_long(sh, g, tid, kLaneThreads);
   __syncthreads();
   const uint32_t xsize = par->xsize;
-  const uint32_t seg = wg * kLaneSegsPerWg + tid / kLanesPerSeg;   // this lane's segment
-  const uint64_t q = (uint64_t)wg * kLaneThreads + tid;             // this lane's piece of the stream
+  // lanes 0 .. kLanesPerSeg - 2: none; lane kLanesPerSeg - 1: the piece before the workgroup's segments; then the segments' pieces
+  const uint32_t first = wg ? kLanesPerSeg - 1 : kLanesPerSeg;      // the lane whose entry is fixed
+  const uint32_t seg = wg * kLaneSegsPerWg + tid / kLanesPerSeg - 1;  // this lane's segment (tid >= kLanesPerSeg)
+  const int64_t q = (int64_t)wg * kLaneSegsPerWg * kLanesPerSeg + tid - kLanesPerSeg;  // this lane's piece of the stream
+  const uint32_t down = (uint32_t)(reinterpret_cast<uintptr_t>(im.data) & 7u);          // the stream is 4-byte aligned
+  const uint64_t bit0 = par->P0 + 8 * down;  // the first token, counted from the stream's first byte rounded down to 8 bytes
+  LaneStream ls;
+  ls.base = reinterpret_cast<const uint64_t *>(im.data - down);
+  ls.nbytes = im.len + down;
+  ls.word0 = (int64_t)(bit0 >> 6) + ((int64_t)wg * kLaneSegsPerWg * kLanesPerSeg - kLanesPerSeg) * (kLaneBits / 64);
+  const uint32_t s0 = (uint32_t)bit0 & 63u;  // every piece starts at this bit of its first word
   // Pieces that start beyond the stream's last byte hold no token of a complete stream (and zeros never fall in step:
   // they repeat one token); a stream that ends before its image does gets its verdict from the one-workgroup form.
-  const bool live = seg < par->nseg, active = live && par->P0 + q * kLaneBits < 8ull * im.len;
-  LaneBits lb;
-  {
-    const uintptr_t at = reinterpret_cast<uintptr_t>(im.data), down = at & 7u;  // the stream is 4-byte aligned
-    lb.base = reinterpret_cast<const uint64_t *>(at - down);
-    lb.nbytes = im.len + down;
-  }
-  const uint64_t piece_bit = par->P0 + q * kLaneBits + 8 * (reinterpret_cast<uintptr_t>(im.data) & 7u);
+  const bool live = tid >= kLanesPerSeg && seg < par->nseg;
+  const bool active = tid >= first && (tid < kLanesPerSeg || live) && par->P0 + (uint64_t)q * kLaneBits < 8ull * im.len;
+  const bool warm_lane = tid < kLanesPerSeg;
   uint32_t in = 0, done_in = 0xffffffffu, out = 0, ntok = 0, npx = 0;
-  // the first lane falls in step over the piece before its own (the stream's first piece starts at the first token)
-  if (tid == 0 && q > 0 && active) in = lane_run<false>(lb, piece_bit, -(int32_t)kLaneBits, 0, g, sh, xsize, true, nullptr, 0, ntok, npx);
   bool settled = false;
   for (uint32_t pass = 0; pass < kLanePasses; pass++) {
     const bool redo = active && in != done_in && in != kParStop;
     if (!__syncthreads_or(redo)) { settled = true; break; }
+    lanes_pass<false>(ls, s0, redo, warm_lane, in, g, sh, xsize, tid, nullptr, 0, out, ntok, npx);
     if (redo) {
-      out = lane_run<false>(lb, piece_bit, (int32_t)in, (int32_t)kLaneBits, g, sh, xsize, false, nullptr, 0, ntok, npx);
       done_in = in;
       sh.exit_off[tid] = (uint8_t)out;
     }
     __syncthreads();
-    if (tid > 0 && active) in = sh.exit_off[tid - 1];
+    if (tid > first && active) in = sh.exit_off[tid - 1];
   }
   // per segment (kLanesPerSeg neighbouring lanes): the first lane that met a token it cannot take ends the records
   const uint32_t sub = lane & (kLanesPerSeg - 1);
-  uint32_t stop = active && (in == kParStop || out == kParStop) ? sub : kLanesPerSeg;
+  uint32_t stop = live && active && (in == kParStop || out == kParStop) ? sub : kLanesPerSeg;
 #pragma unroll
   for (uint32_t o = 1; o < kLanesPerSeg; o <<= 1) {
     const uint32_t t = (uint32_t)__shfl_xor((int)stop, (int)o, 64);
     stop = t < stop ? t : stop;
   }
-  if (!active || sub > stop || in == kParStop) { ntok = 0; npx = 0; }
+  if (!live || !active || sub > stop || in == kParStop) { ntok = 0; npx = 0; }
   uint32_t itok = ntok, all_px = npx;
 #pragma unroll
   for (uint32_t o = 1; o < kLanesPerSeg; o <<= 1) {
@@ -1268,16 +1316,17 @@ __global__ __launch_bounds__(kLaneThreads) void k_par_scout_lanes(const DecImage
   if (!settled) flags |= 2;                 // not in step: the entry maps decode this stream
   if (all_tok > kParRecCap) flags |= 2;     // more tokens than records
   if (stop < kLanesPerSeg) flags |= 1;      // the stream goes to the one-workgroup form if the image is not complete by then
-  if (!(flags & 2) && ntok) {
+  const bool write = !(flags & 2) && ntok;
+  if (__syncthreads_or(write)) {
     const uint32_t off = itok - ntok;
-    uint32_t t2, p2;
-    (void)lane_run<true>(lb, piece_bit, (int32_t)in, (int32_t)kLaneBits, g, sh, xsize, false, par->records + (size_t)seg * kParRecCap + off,
-                         kParRecCap - off, t2, p2);
+    uint32_t o2 = 0, t2 = 0, p2 = 0;
+    lanes_pass<true>(ls, s0, write, false, in, g, sh, xsize, tid, par->records + (size_t)(live ? seg : 0u) * kParRecCap + off,
+                     off < kParRecCap ? kParRecCap - off : 0u, o2, t2, p2);
   }
   if (live) {
     uint64_t *slot = par->segmap + (size_t)seg * 64;
     if (sub == kLanesPerSeg - 1) {
-      slot[0] = (uint64_t)(stop < kLanesPerSeg ? 0u : out) | ((uint64_t)all_px << 32);
+      slot[0] = (uint64_t)(stop < kLanesPerSeg || !active ? 0u : out) | ((uint64_t)all_px << 32);
       slot[2] = flags;
     }
     if (sub == 0) slot[1] = (uint64_t)(in == kParStop ? 0u : in) | ((uint64_t)all_tok << 32);
@@ -1374,29 +1423,39 @@ __global__ __launch_bounds__(kWgThreads) void k_par_place(const DecImage *__rest
   if (bad) par_fail(par, kErrInvalidVp8l);
 }
 
-// sb_first / units as for the inverse transforms: a unit of kUnit pixels per workgroup
-__global__ __launch_bounds__(256) void k_par_jump(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t pass) {
-  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb);
-  ParImage *par = imgs[img].par;
-  if (!par || !par->active || par->status != kOk) return;
-  if (pass > 0 && !par->changed[pass - 1]) return;  // the pass before left nothing open
-  const uint64_t p0 = (uint64_t)(unit - sb_first[img] * kUnitsPerSuper) * kUnit;
-  uint32_t *srcg = par->srcg;
-  const uint32_t total = par->total;
-  bool open = false;
-  for (uint32_t k = 0; k < kUnit / 256; k++) {
-    const uint64_t p = p0 + k * 256 + threadIdx.x;
-    if (p < total) {
-      const uint32_t v = srcg[p];
-      if (!(v & kFinalBit)) {
-        // the source's own source; read while its owner replaces it, it is the old or the new one: both lead to the same literal
-        const uint32_t t = __hip_atomic_load(&srcg[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&srcg[p], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        open = open || !(t & kFinalBit);
+// sb_first / units as for the inverse transforms: a unit of kUnit pixels at a time.  The grid is a few workgroups per
+// CU that stride over the units: most of the passes find nothing left to do, and a launch of one workgroup per unit
+// that only looks and leaves took 0.18 ms for a gigapixel (29 of 32 passes, 5 ms of a 48 ms batch).
+constexpr uint32_t kParJumpGrid = 4096;
+__global__ __launch_bounds__(256) void k_par_jump(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t pass,
+                                                  uint32_t units, uint32_t *__restrict__ any_open) {
+  if (pass > 0 && !any_open[pass - 1]) return;  // no image of the call has an open chain left
+  for (uint32_t unit = blockIdx.x; unit < units; unit += gridDim.x) {
+    const uint32_t sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb);
+    ParImage *par = imgs[img].par;
+    if (!par || !par->active || par->status != kOk) continue;
+    if (pass > 0 && !par->changed[pass - 1]) continue;  // the pass before left nothing open
+    const uint64_t p0 = (uint64_t)(unit - sb_first[img] * kUnitsPerSuper) * kUnit;
+    uint32_t *srcg = par->srcg;
+    const uint32_t total = par->total;
+    bool open = false;
+    for (uint32_t k = 0; k < kUnit / 256; k++) {
+      const uint64_t p = p0 + k * 256 + threadIdx.x;
+      if (p < total) {
+        const uint32_t v = srcg[p];
+        if (!(v & kFinalBit)) {
+          // the source's own source, up to three steps on; read while its owner replaces it, it is the old or the new
+          // one: both lead to the same literal
+          uint32_t t = __hip_atomic_load(&srcg[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!(t & kFinalBit)) t = __hip_atomic_load(&srcg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!(t & kFinalBit)) t = __hip_atomic_load(&srcg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&srcg[p], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          open = open || !(t & kFinalBit);
+        }
       }
     }
+    if (__syncthreads_or(open) && threadIdx.x == 0) { par->changed[pass] = 1; any_open[pass] = 1; }
   }
-  if (__syncthreads_or(open) && threadIdx.x == 0) par->changed[pass] = 1;
 }
 
 __global__ __launch_bounds__(256) void k_par_gather(const DecImage *__restrict__ imgs, DecResult *__restrict__ res, const uint32_t *__restrict__ sb_first,
@@ -1793,7 +1852,7 @@ struct vp8l_decoder {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
   DeviceBuffer d_imgs, d_res, d_sbfirst, d_aux, d_scratch, d_groups, d_cache, d_sorted;
-  DeviceBuffer d_par, d_srcg, d_segmap, d_segidx, d_segfirst, d_lanefirst, d_records;  // the segment kernels' workspace
+  DeviceBuffer d_par, d_srcg, d_segmap, d_segidx, d_segfirst, d_lanefirst, d_jumpflags, d_records;  // the segment kernels' workspace
   DeviceBuffer d_progress;  // the banded predictor inverse: pixels finished per band
   double last_seconds = 0;
   int threads_per_stream = 0;  // 0: chosen per call
@@ -1843,7 +1902,7 @@ extern "C" void vp8l_decoder_destroy(vp8l_decoder *d) {
   if (d->ev0) (void)hipEventDestroy(d->ev0);
   if (d->ev1) (void)hipEventDestroy(d->ev1);
   DeviceBuffer *bufs[] = {&d->d_imgs, &d->d_res, &d->d_sbfirst, &d->d_aux, &d->d_scratch, &d->d_groups, &d->d_cache, &d->d_sorted,
-                          &d->d_par, &d->d_srcg, &d->d_segmap, &d->d_segidx, &d->d_segfirst, &d->d_lanefirst, &d->d_records, &d->d_progress};
+                          &d->d_par, &d->d_srcg, &d->d_segmap, &d->d_segidx, &d->d_segfirst, &d->d_lanefirst, &d->d_jumpflags, &d->d_records, &d->d_progress};
   for (auto *b : bufs) b->release();
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
@@ -1910,7 +1969,7 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
   if (!ok) return VP8L_ERR_NO_MEMORY;
   if (whole_device) {
     if (!d->d_par.reserve(m * sizeof(ParImage)) || !d->d_srcg.reserve(px_total * 4) || !d->d_segmap.reserve(seg_total * 64 * 8) ||
-        !d->d_segidx.reserve((seg_total + m) * 2 * 4) || !d->d_segfirst.reserve((m + 1) * 4) || !d->d_lanefirst.reserve((m + 1) * 4) ||
+        !d->d_segidx.reserve((seg_total + m) * 2 * 4) || !d->d_segfirst.reserve((m + 1) * 4) || !d->d_lanefirst.reserve((m + 1) * 4) || !d->d_jumpflags.reserve(kParJumpPasses * 4) ||
         (whole_mode == 1 && !d->d_records.reserve(seg_total * kParRecCap * 8)))
       return VP8L_ERR_NO_MEMORY;
     for (uint32_t k = 0; k < m; k++) {
@@ -1940,7 +1999,8 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
   if (whole_device &&
       (!hip_ok(hipMemcpyAsync(d->d_par.ptr, pars.data(), m * sizeof(ParImage), hipMemcpyHostToDevice, s), "upload segment workspace") ||
        !hip_ok(hipMemcpyAsync(d->d_segfirst.ptr, seg_first.data(), (m + 1) * 4, hipMemcpyHostToDevice, s), "upload segment table") ||
-       !hip_ok(hipMemcpyAsync(d->d_lanefirst.ptr, lane_first.data(), (m + 1) * 4, hipMemcpyHostToDevice, s), "upload piece table")))
+       !hip_ok(hipMemcpyAsync(d->d_lanefirst.ptr, lane_first.data(), (m + 1) * 4, hipMemcpyHostToDevice, s), "upload piece table") ||
+       !hip_ok(hipMemsetAsync(d->d_jumpflags.ptr, 0, kParJumpPasses * 4, s), "clear pass flags")))
     return VP8L_ERR_HIP;
   const uint32_t gunits = (uint32_t)(sb_total * kUnitsPerSuper);
   (void)hipEventRecord(d->ev0, s);
@@ -1961,7 +2021,8 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
       hipLaunchKernelGGL(k_par_chain, dim3(m), dim3(256), 0, s, dimgs);
       hipLaunchKernelGGL(k_par_pixels, dim3((uint32_t)seg_total), dim3(kWgThreads), 0, s, dimgs, segf, m);
     }
-    for (uint32_t pass = 0; pass < kParJumpPasses; pass++) hipLaunchKernelGGL(k_par_jump, dim3(gunits), dim3(256), 0, s, dimgs, sbf, m, pass);
+    for (uint32_t pass = 0; pass < kParJumpPasses; pass++)
+      hipLaunchKernelGGL(k_par_jump, dim3(std::min(gunits, kParJumpGrid)), dim3(256), 0, s, dimgs, sbf, m, pass, gunits, d->d_jumpflags.as<uint32_t>());
     hipLaunchKernelGGL(k_par_gather, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m);
     hipLaunchKernelGGL(k_par_finish, dim3(m), dim3(1), 0, s, dimgs, dres);
   }
