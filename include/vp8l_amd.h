@@ -149,6 +149,8 @@ enum { VP8L_DEC_OPT_THREADS_PER_STREAM = 1, VP8L_DEC_OPT_WHOLE_DEVICE = 2, VP8L_
 int vp8l_decoder_set_option(vp8l_decoder *dec, int option, int value);
 /* Streams of the last call on the context that the segment kernels decoded. */
 long vp8l_decoder_last_whole_device_streams(const vp8l_decoder *dec);
+/* ... and of those, the streams whose scouts were accepted (the others were decoded again with the entry maps). */
+long vp8l_decoder_last_scout_streams(const vp8l_decoder *dec);
 
 /* Seconds spent in the device part of the last call on the context (HIP events on the
  * context's stream), and per-kernel-stage seconds for the encoder

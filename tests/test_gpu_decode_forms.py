@@ -11,22 +11,25 @@ import webp_amd
 pytestmark = pytest.mark.gpu
 
 
-def decode_with(threads, streams, whole_device=1, used=None):
-    """Decodes through the device-memory entry point with the given form; returns [(status, pixels)]."""
+def decode_with(threads, streams, whole_device=1, used=None, scout_form=0, shift=0):
+    """Decodes through the device-memory entry point with the given form; returns [(status, pixels)].  `shift`: the
+    streams start this many bytes (a multiple of 4) into their allocations, which end right behind them."""
     dec = webp_amd.Decoder()
     dec.set_threads_per_stream(threads)
     dec.set_whole_device(whole_device)
+    dec.set_scout_form(scout_form)
     infos = [webp_amd.get_info(s) for s in streams]
     d_streams = []
     for s in streams:
-        buf = np.frombuffer(s + b"\0" * ((-len(s)) % 4), dtype=np.uint8)
+        buf = np.frombuffer(b"\xA5" * shift + s + b"\0" * ((-len(s)) % 4), dtype=np.uint8)
         d_streams.append(torch.from_numpy(buf.copy()).cuda())
     d_out = [torch.full((w * h,), 0x5A5A5A5A, dtype=torch.int32, device="cuda") for w, h in infos]
-    st = dec.decode_device([d.data_ptr() for d in d_streams], [len(s) for s in streams], [w for w, _ in infos],
+    st = dec.decode_device([d.data_ptr() + shift for d in d_streams], [len(s) for s in streams], [w for w, _ in infos],
                            [h for _, h in infos], [d.data_ptr() for d in d_out])
     torch.cuda.synchronize()
     if used is not None:
         used.append(dec.last_whole_device_streams())
+        used.append(dec.last_scout_streams())
     return [(int(st[i]), d_out[i].cpu().numpy().view(np.uint32)) for i in range(len(streams))]
 
 
@@ -206,8 +209,10 @@ def test_both_forms_agree_on_encoder_streams():
         assert np.array_equal(pb, img), k
 
 
-def test_whole_device_form():
-    """Large streams cut into segments and decoded by many workgroups: same pixels and verdicts."""
+@pytest.mark.parametrize("scout_form,shift", [(0, 0), (0, 4), (1, 0)])
+def test_whole_device_form(scout_form, shift):
+    """Large streams cut into segments and decoded by many workgroups: same pixels and verdicts, with either form of
+    the scouts, and with streams that start 4 bytes off an 8-byte boundary (the lane form reads 8-byte words)."""
     cases = [(3, 1100, 700), (4, 1100, 700), (5, 1024, 600), (4, 4096, 40), (3, 300, 300), (3, 40, 40), (4, 2000, 1100)]
     imgs = [O.gen_image(m, w, h, 700 + w, 200) for m, w, h in cases]
     flat = np.full(700 * 500, 0xFF336699, dtype=np.uint32)
@@ -226,11 +231,12 @@ def test_whole_device_form():
         streams.append(s)
         imgs.append(imgs[0])
     used = []
-    res = decode_with(1024, streams, whole_device=2, used=used)
+    res = decode_with(1024, streams, whole_device=2, used=used, scout_form=scout_form, shift=shift)
     for k, ((st, px), img) in enumerate(zip(res, imgs)):
         assert st == 0, (k, st)
         assert np.array_equal(px, img), k
-    assert used[0] >= 7, used  # the large one-group streams went through the segment kernels
+    assert used[0] >= 7, used  # the large one-group streams went through the segment kernels ...
+    assert used[1] >= 6, used  # ... and the scouts of the generated images were accepted (the nearly flat one repeats one token)
     # damaged streams: the verdict and the pixels of the one-workgroup form
     rng = np.random.default_rng(12)
     bad = []
@@ -243,7 +249,7 @@ def test_whole_device_form():
                 pos = int(rng.integers(len(b) // 4, len(b)))
                 b[pos] ^= 1 << int(rng.integers(0, 8))
             bad.append(bytes(b))
-    a = decode_with(1024, bad, whole_device=2)
+    a = decode_with(1024, bad, whole_device=2, scout_form=scout_form, shift=shift)
     b = decode_with(1024, bad, whole_device=1)
     for k, ((sa, pa), (sb, pb)) in enumerate(zip(a, b)):
         assert sa == sb, (k, sa, sb)
@@ -251,20 +257,22 @@ def test_whole_device_form():
             assert np.array_equal(pa, pb), k
 
 
-def test_whole_device_handmade_tokens():
+@pytest.mark.parametrize("scout_form", [0, 1])
+def test_whole_device_handmade_tokens(scout_form):
     streams, expect = [], []
     for w, h, toks in handmade_cases():
         s, e = handmade_stream(w, h, toks)
         rc0, ref, w0, h0 = O.decode(s)
         streams.append(s)
         expect.append((rc0, ref))
-    for (st, px), (rc0, ref) in zip(decode_with(1024, streams, whole_device=2), expect):
+    for (st, px), (rc0, ref) in zip(decode_with(1024, streams, whole_device=2, scout_form=scout_form), expect):
         assert st == rc0, (st, rc0)
         if rc0 == 0:
             assert np.array_equal(px, ref)
 
 
-def test_whole_device_when_scouts_cannot_fall_in_step():
+@pytest.mark.parametrize("scout_form", [0, 1])
+def test_whole_device_when_scouts_cannot_fall_in_step(scout_form):
     """Uniform random 7-bit values give codes of one length: a decoder started at a wrong bit never meets the token chain,
     so the scouts are rejected and the entry maps decode the stream; same pixels.  (All 256 byte values would give the
     256 x 8-bit code that the reference itself cannot read back.)"""
@@ -278,7 +286,18 @@ def test_whole_device_when_scouts_cannot_fall_in_step():
         assert rc == 0
         streams.append(s)
     used = []
-    res = decode_with(1024, streams, whole_device=2, used=used)
+    res = decode_with(1024, streams, whole_device=2, used=used, scout_form=scout_form)
     for (st, px), im in zip(res, (img, img2)):
         assert st == 0 and np.array_equal(px, im)
-    assert used[0] == 2, used
+    assert used[0] == 2, used  # green and alpha have codes of one length, red and blue not quite: some scouts may fall in step
+    # all four codes of one length (red and blue are green plus uniform noise): tokens of 28 bits, no scout of either
+    # form can fall in step
+    g = rng.integers(0, 128, size=w * h, dtype=np.uint32)
+    img3 = (rng.integers(0, 128, size=w * h, dtype=np.uint32) << 24) | (((g + rng.integers(0, 128, size=w * h, dtype=np.uint32)) & 255) << 16) \
+        | (g << 8) | ((g + rng.integers(0, 128, size=w * h, dtype=np.uint32)) & 255)
+    rc, s3 = O.encode(img3, w, h)
+    assert rc == 0
+    used = []
+    (st, px), = decode_with(1024, [s3], whole_device=2, used=used, scout_form=scout_form)
+    assert st == 0 and np.array_equal(px, img3)
+    assert used == [1, 0], used

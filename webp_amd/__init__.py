@@ -30,6 +30,7 @@ STATUS_NAMES = {
 STAGE_RESIDUAL, STAGE_MATCH, STAGE_HISTO, STAGE_CODELEN, STAGE_INFO, STAGE_PRED_MODES, STAGE_CROSS_ELEMS = range(7)
 DEC_OPT_THREADS_PER_STREAM = 1
 DEC_OPT_WHOLE_DEVICE = 2
+DEC_OPT_SCOUT_FORM = 3
 ENCODE_STAGES = ("palette", "transform", "match", "parse", "histogram", "header", "bitcount_scan", "emit",
                  "match_fallback")  # the last one is the part of "match" spent in the exhaustive kernel
 
@@ -95,6 +96,8 @@ def lib():
         L.vp8l_decoder_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.vp8l_decoder_last_whole_device_streams.argtypes = [C.c_void_p]
         L.vp8l_decoder_last_whole_device_streams.restype = C.c_long
+        L.vp8l_decoder_last_scout_streams.argtypes = [C.c_void_p]
+        L.vp8l_decoder_last_scout_streams.restype = C.c_long
         L.vp8l_generate_device.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         _lib = L
     return _lib
@@ -108,6 +111,7 @@ EXPORTED_SYMBOLS = (
     "vp8l_decoder_last_device_seconds", "vp8l_generate_device", "vp8l_encoder_set_option",
     "vp8l_encoder_last_dense_tiles", "vp8l_decoder_set_option",
     "vp8l_decoder_last_whole_device_streams",
+    "vp8l_decoder_last_scout_streams",
 )
 
 
@@ -343,8 +347,18 @@ class Decoder:
         if rc != OK:
             raise Vp8lError(rc, "vp8l_decoder_set_option")
 
+    def set_scout_form(self, form):
+        """How the segment kernels find a segment's tokens: 0 = a lane per piece of 8192 bits (default), 1 = a token at
+        every bit offset (same pixels)."""
+        rc = lib().vp8l_decoder_set_option(self._h, DEC_OPT_SCOUT_FORM, int(form))
+        if rc != OK:
+            raise Vp8lError(rc, "vp8l_decoder_set_option")
+
     def last_whole_device_streams(self):
         return int(lib().vp8l_decoder_last_whole_device_streams(self._h))
+
+    def last_scout_streams(self):
+        return int(lib().vp8l_decoder_last_scout_streams(self._h))
 
     def set_threads_per_stream(self, threads):
         """0 or 1024 = a workgroup per stream (default), 64 = a wave per stream (same pixels either way)."""

@@ -1858,6 +1858,7 @@ struct vp8l_decoder {
   int threads_per_stream = 0;  // 0: chosen per call
   int whole_device = 0;        // 0: chosen per call, 1: never, 2: whenever the stream qualifies
   uint32_t last_whole_device = 0;  // streams of the last call that the segment kernels decoded
+  uint32_t last_scouted = 0;       // ... of them, with the scouts' token records (the others needed the entry maps)
   int scout_form = 0;          // 0: a lane per piece of a segment (k_par_scout_lanes), 1: a token at every bit offset (k_par_scout)
 };
 
@@ -2080,6 +2081,7 @@ extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8
   for (uint32_t i : pending) stream_bytes += len[i];
   const bool whole_device = d->threads_per_stream != 64 && (d->whole_device == 2 || (d->whole_device == 0 && stream_bytes >= (2u << 20)));
   d->last_whole_device = 0;
+  d->last_scouted = 0;
   // Passes: first everything (whole-device streams with scouts), then again what a pass handed on: streams whose
   // scouts were not in step (entry maps), streams the segment kernels cannot take (one workgroup), streams with more
   // Huffman groups than the pass provided.
@@ -2120,6 +2122,7 @@ extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8
       } else {
         status[t.idx[k]] = r.status;
         if (t.mode && r.pad == 1) d->last_whole_device++;
+        if (t.mode == 1 && r.pad == 1) d->last_scouted++;
       }
     }
     for (Todo *n2 : {&more_groups, &with_maps, &one_workgroup, &one_block_predictor})
@@ -2129,5 +2132,7 @@ extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8
 }
 
 extern "C" long vp8l_decoder_last_whole_device_streams(const vp8l_decoder *d) { return d ? (long)d->last_whole_device : 0; }
+
+extern "C" long vp8l_decoder_last_scout_streams(const vp8l_decoder *d) { return d ? (long)d->last_scouted : 0; }
 
 extern "C" double vp8l_decoder_last_device_seconds(const vp8l_decoder *d) { return d ? d->last_seconds : 0.0; }
