@@ -136,15 +136,16 @@ int vp8l_decoder_decode_device(vp8l_decoder *dec, size_t n, const uint8_t *const
  * several times slower: only faster for thousands of small streams of noisy content).  Identical pixels. */
 /* VP8L_DEC_OPT_WHOLE_DEVICE: streams are cut into segments of 65536 bits that many workgroups decode (a scout per
  * segment records its tokens, a serial check accepts them, pointer jumping over the pixels resolves the references; a
- * 3840x2160 stream in 3 ms instead of half a second, 6.7 GP/s instead of 4.2 for a large batch).  0 (default) = when a
+ * 3840x2160 stream in 3 ms instead of half a second, 29 GP/s instead of 4.2 for a large batch).  0 (default) = when a
  * call has at least 2 MiB of streams; 1 = never; 2 = always.  Images below 65536 pixels, streams with a colour cache,
  * several Huffman groups or tokens the segment decoder does not take are decoded by one workgroup each as before.
  * Workspace: 16 bytes per stream byte and 4 bytes per pixel, in passes of at most 1 GiB of streams.  Identical pixels
  * and verdicts. */
-/* VP8L_DEC_OPT_SCOUT_FORM: how a segment's scout finds its tokens.  0 (default) = the segment is cut into pieces of 256
+/* VP8L_DEC_OPT_SCOUT_FORM: how a segment's scout finds its tokens.  0 (default) = the segment is cut into pieces of 8192
  * bits, a lane decodes a piece token after token, first from a guessed entry and again from where the lane before it
  * left, until no entry changes; 1 = a token is decoded at every bit offset and the chain is found by pointer jumping
- * (the first version, several times slower).  Identical records, pixels and verdicts. */
+ * (the first version: a quarter faster for a single stream, three to four times slower for batches).  Identical
+ * pixels and verdicts. */
 enum { VP8L_DEC_OPT_THREADS_PER_STREAM = 1, VP8L_DEC_OPT_WHOLE_DEVICE = 2, VP8L_DEC_OPT_SCOUT_FORM = 3 };
 int vp8l_decoder_set_option(vp8l_decoder *dec, int option, int value);
 /* Streams of the last call on the context that the segment kernels decoded. */
