@@ -1127,6 +1127,7 @@ __global__ __launch_bounds__(kWgThreads, 8) void k_par_scout(const DecImage *__r
     slot[0] = (uint64_t)(P - seg_end) | ((uint64_t)npx << 32);
     slot[1] = (uint64_t)entry | ((uint64_t)ntok << 32);
     slot[2] = flags;
+    slot[3] = 0;  // the records lie in one piece
   }
 }
 
@@ -1156,6 +1157,9 @@ constexpr uint32_t kLaneRounds = kLaneBits / kLaneChunkBits;
 constexpr uint32_t kLaneRing = 2 * kLaneChunkWords;                   // the chunk being decoded and the one after it
 constexpr uint32_t kLaneRingStride = kLaneThreads + 1;                // words of one lane in different banks
 constexpr uint32_t kLanePasses = 8;   // entries still changing after this many passes: the stream does not fall in step
+constexpr uint32_t kLaneGuessRound = kLaneRounds / 2;                 // the guess of a lane's exit starts here
+constexpr uint32_t kLaneRecCap = kParRecCap / kLanesPerSeg;           // token records per lane: tokens of 4 bits fill them
+static_assert(4 + kLanesPerSeg <= 64, "a segment's slots hold the lanes' record counts");
 static_assert(kLaneBits < kParSegBits && (kLanesPerSeg & (kLanesPerSeg - 1)) == 0 && kLanesPerSeg <= 64, "the lanes of a segment sit in one wave");
 static_assert(kLaneThreads % 64 == 0 && kLaneThreads >= kNumCodes * kWgLongSlots, "whole waves; one thread per long-code slot");
 static_assert(64 % kLaneChunkWords == 0 && kLaneBits % kLaneChunkBits == 0 && kLaneBits % 64 == 0, "chunks");
@@ -1204,24 +1208,25 @@ __device__ __forceinline__ void lane_ring_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One pass of the whole workgroup over its pieces; every thread calls it (the waves do not wait for each other).  A lane with `run` decodes the tokens
-// from bit `in` of its piece until one starts in the next piece (`out`: how far in), or until it meets a token it
-// cannot take (out = kParStop; a warm-up lane moves on by a bit instead).  kRecord: the records go to rec[0..cap).
+// One pass of the whole workgroup over its pieces; every thread calls it (the waves do not wait for each other).  A
+// lane with `run` decodes the tokens from bit `in` of round r0 of its piece until one starts in the next piece (`out`:
+// how far in), or until it meets a token it cannot take (out = kParStop; a warm-up lane moves on by a bit instead).
+// kRecord: the records go to rec[0..cap).
 template <bool kRecord>
 __device__ __forceinline__ void lanes_pass(const LaneStream &ls, uint32_t s0, bool run, bool warm, uint32_t in, const VP8L_LDS GroupTables &g,
                                            VP8L_LDS LaneShared &sh, uint32_t xsize, uint32_t tid, uint64_t *rec, uint32_t cap,
-                                           uint32_t &out, uint32_t &ntok, uint32_t &npx) {
+                                           uint32_t r0, uint32_t &out, uint32_t &ntok, uint32_t &npx) {
   uint64_t regs[kLaneChunkWords];
-  ls.load(0, tid, regs);
-  ls.store(0, tid, regs, sh);
-  ls.load(1, tid, regs);
-  ls.store(1, tid, regs, sh);
+  ls.load(r0, tid, regs);
+  ls.store(r0, tid, regs, sh);
+  ls.load(r0 + 1, tid, regs);
+  ls.store(r0 + 1, tid, regs, sh);
   lane_ring_sync();
-  uint32_t rel = in, k = (s0 + in) >> 6, s = (s0 + in) & 63u, tok = 0, px = 0;
+  uint32_t rel = r0 * kLaneChunkBits + in, k = (s0 + rel) >> 6, s = (s0 + rel) & 63u, tok = 0, px = 0;
   uint64_t A = sh.ring[k % kLaneRing][tid], B = sh.ring[(k + 1) % kLaneRing][tid], C = sh.ring[(k + 2) % kLaneRing][tid];
   bool stopped = false;
 #pragma unroll 1
-  for (uint32_t r = 0; r < kLaneRounds; r++) {
+  for (uint32_t r = r0; r < kLaneRounds; r++) {
     const bool more = r + 2 <= kLaneRounds;   // the last round reads into the first chunk of the next piece
     if (more) ls.load(r + 2, tid, regs);
     if (run && !stopped) {
@@ -1282,12 +1287,21 @@ __global__ __launch_bounds__(kLaneThreads, 5) void k_par_scout_lanes(const DecIm
   const bool live = tid >= kLanesPerSeg && seg < par->nseg;
   const bool active = tid >= first && (tid < kLanesPerSeg || live) && par->P0 + (uint64_t)q * kLaneBits < 8ull * im.len;
   const bool warm_lane = tid < kLanesPerSeg;
+  const uint32_t sub = lane & (kLanesPerSeg - 1);
+  // this lane's part of its segment's records: written again whenever the lane decodes again
+  uint64_t *rec = par->records + (size_t)(live ? seg : 0u) * kParRecCap + sub * kLaneRecCap;
   uint32_t in = 0, done_in = 0xffffffffu, out = 0, ntok = 0, npx = 0;
+  // The guess: where a decoder started in the middle of the piece leaves it.  It has fallen in step by then nearly
+  // always, so this is where the true chain leaves the piece, found at half the price of a pass.
+  lanes_pass<false>(ls, s0, active, true, 0, g, sh, xsize, tid, nullptr, 0, kLaneGuessRound, out, ntok, npx);
+  if (active) sh.exit_off[tid] = (uint8_t)out;
+  __syncthreads();
+  if (tid > first && active) in = sh.exit_off[tid - 1];
   bool settled = false;
   for (uint32_t pass = 0; pass < kLanePasses; pass++) {
     const bool redo = active && in != done_in && in != kParStop;
     if (!__syncthreads_or(redo)) { settled = true; break; }
-    lanes_pass<false>(ls, s0, redo, warm_lane, in, g, sh, xsize, tid, nullptr, 0, out, ntok, npx);
+    lanes_pass<true>(ls, s0, redo, warm_lane, in, g, sh, xsize, tid, rec, live ? kLaneRecCap : 0u, 0, out, ntok, npx);
     if (redo) {
       done_in = in;
       sh.exit_off[tid] = (uint8_t)out;
@@ -1296,7 +1310,6 @@ __global__ __launch_bounds__(kLaneThreads, 5) void k_par_scout_lanes(const DecIm
     if (tid > first && active) in = sh.exit_off[tid - 1];
   }
   // per segment (kLanesPerSeg neighbouring lanes): the first lane that met a token it cannot take ends the records
-  const uint32_t sub = lane & (kLanesPerSeg - 1);
   uint32_t stop = live && active && (in == kParStop || out == kParStop) ? sub : kLanesPerSeg;
 #pragma unroll
   for (uint32_t o = 1; o < kLanesPerSeg; o <<= 1) {
@@ -1312,19 +1325,17 @@ __global__ __launch_bounds__(kLaneThreads, 5) void k_par_scout_lanes(const DecIm
     all_px += (uint32_t)__shfl_xor((int)all_px, (int)o, 64);
   }
   const uint32_t all_tok = (uint32_t)__shfl((int)itok, (int)(lane | (kLanesPerSeg - 1)), 64);
+  uint32_t over = ntok > kLaneRecCap ? 1u : 0u;  // a lane with more tokens than records
+#pragma unroll
+  for (uint32_t o = 1; o < kLanesPerSeg; o <<= 1) over |= (uint32_t)__shfl_xor((int)over, (int)o, 64);
   uint32_t flags = 0;
   if (!settled) flags |= 2;                 // not in step: the entry maps decode this stream
-  if (all_tok > kParRecCap) flags |= 2;     // more tokens than records
+  if (over) flags |= 2;
   if (stop < kLanesPerSeg) flags |= 1;      // the stream goes to the one-workgroup form if the image is not complete by then
-  const bool write = !(flags & 2) && ntok;
-  if (__syncthreads_or(write)) {
-    const uint32_t off = itok - ntok;
-    uint32_t o2 = 0, t2 = 0, p2 = 0;
-    lanes_pass<true>(ls, s0, write, false, in, g, sh, xsize, tid, par->records + (size_t)(live ? seg : 0u) * kParRecCap + off,
-                     off < kParRecCap ? kParRecCap - off : 0u, o2, t2, p2);
-  }
   if (live) {
     uint64_t *slot = par->segmap + (size_t)seg * 64;
+    slot[3] = 1;                            // the records lie in kLanesPerSeg parts ...
+    slot[4 + sub] = itok - ntok;            // ... and this many tokens come before this lane's part
     if (sub == kLanesPerSeg - 1) {
       slot[0] = (uint64_t)(stop < kLanesPerSeg || !active ? 0u : out) | ((uint64_t)all_px << 32);
       slot[2] = flags;
@@ -1378,13 +1389,29 @@ __global__ __launch_bounds__(kWgThreads) void k_par_place(const DecImage *__rest
   const uint32_t total = par->total;
   uint32_t fill = par->segbase[seg];
   if (fill >= total) return;
-  const uint32_t ntok = (uint32_t)(par->segmap[(size_t)seg * 64 + 1] >> 32);
+  const uint64_t *slot = par->segmap + (size_t)seg * 64;
+  const uint32_t ntok = (uint32_t)(slot[1] >> 32);
   const uint64_t *rec = par->records + (size_t)seg * kParRecCap;
+  // the lane scouts leave the records in kLanesPerSeg parts: tokens before each part
+  const bool parts = slot[3] != 0;
+  uint32_t before_part[kLanesPerSeg];
+#pragma unroll
+  for (uint32_t j = 0; j < kLanesPerSeg; j++) before_part[j] = parts ? (uint32_t)slot[4 + j] : 0u;
   uint32_t *dst = par->dst, *srcg = par->srcg;
   bool bad = false;
   for (uint32_t t0 = 0; t0 < ntok && fill < total; t0 += kWgThreads) {
     const uint32_t i = t0 + tid;
-    const uint64_t rc = i < ntok ? rec[i] : 0ull;
+    uint32_t at = i;
+    if (parts) {
+      uint32_t part = 0;
+#pragma unroll
+      for (uint32_t j = 1; j < kLanesPerSeg; j++) part += before_part[j] <= i ? 1u : 0u;
+      uint32_t b4 = 0;
+#pragma unroll
+      for (uint32_t j = 1; j < kLanesPerSeg; j++) b4 = part == j ? before_part[j] : b4;
+      at = part * kLaneRecCap + (i - b4);
+    }
+    const uint64_t rc = i < ntok ? rec[at] : 0ull;
     const uint32_t val = (uint32_t)rc, cnt = (uint32_t)(rc >> 32) & 0xffu;
     const bool ref = (rc >> 40) & 1ull;
     const uint32_t incl = wave_incl_scan_u32(cnt, (int)lane);
