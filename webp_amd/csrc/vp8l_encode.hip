@@ -588,7 +588,10 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
                                                      uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
   __shared__ __attribute__((aligned(16))) uint32_t px[kSpSources + kMaxLen + 4];
   __shared__ uint16_t runlen[kSpSources + kMaxLen];  // pixels equal to this one from here on (within the window)
-  __shared__ uint32_t cursor[kSpBuckets];  // counts, then insert positions; after the scatter cursor[h] = end of bucket h
+  // counts, then insert positions; after the scatter cursor[h] = end of bucket h.  16 bits each (at most kSpSources), two to
+  // a word that the LDS atomics add to: 8 KB less LDS lets a fourth workgroup onto the CU
+  __shared__ uint32_t cursor2[kSpBuckets / 2];
+  const uint16_t *cursor = reinterpret_cast<const uint16_t *>(cursor2);
   __shared__ uint32_t items[kSpSources];   // (low bits of the mixed pixel) << 11 | index in px
   __shared__ uint32_t wsum[kSpWaves];
   __shared__ uint32_t wmin[kSpWaves];
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   const uint64_t pos0 = imgs[img].pos0;
   const uint32_t *data = pix + pos0;
   const uint32_t lane = tid & 63, wave = tid >> 6;
-  for (uint32_t i = tid; i < kSpBuckets; i += kSpThreads) cursor[i] = 0;
+  for (uint32_t i = tid; i < kSpBuckets / 2; i += kSpThreads) cursor2[i] = 0;
   if (tid == 0) { s_abort = 0; s_inside = 0; s_nonempty = 0; s_heavy = 0; }
   // lo is a multiple of 4 (a and kWindow are) and the pixel array has readable slack past M: 16-byte loads
   if (st[img].fused) {
@@ -689,12 +692,21 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   }
 #pragma unroll
   for (uint32_t k = 0; k < kSpSources / kSpThreads; k++)
-    if ((first_of_run >> k) & 1u) atomicAdd(&cursor[mixed[k] >> (32 - kSpPosBits)], 1u);
+    if ((first_of_run >> k) & 1u) {
+      const uint32_t hb = mixed[k] >> (32 - kSpPosBits);
+      atomicAdd(&cursor2[hb >> 1], 1u << (16 * (hb & 1u)));
+    }
   __syncthreads();
   // exclusive scan of the bucket counts (8 per thread)
   uint32_t c[8], sum = 0, mx = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) { c[k] = cursor[tid * 8 + k]; sum += c[k]; mx = c[k] > mx ? c[k] : mx; }
+  for (int k = 0; k < 4; k++) {
+    const uint32_t two = cursor2[tid * 4 + k];
+    c[2 * k] = two & 0xffffu;
+    c[2 * k + 1] = two >> 16;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) { sum += c[k]; mx = c[k] > mx ? c[k] : mx; }
   const uint32_t incl = wave_incl_scan_u32(sum, (int)lane);
   if (lane == 63) wsum[wave] = incl;
   if (mx > kSpMaxBucket) s_abort = 1;
@@ -717,12 +729,19 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
     if (entries > kSpMaxPerValue * s_nonempty) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
   }
 #pragma unroll
-  for (int k = 0; k < 8; k++) { cursor[tid * 8 + k] = run; run += c[k]; }
+  for (int k = 0; k < 4; k++) {
+    const uint32_t lo16 = run, hi16 = run + c[2 * k];
+    cursor2[tid * 4 + k] = lo16 | (hi16 << 16);
+    run = hi16 + c[2 * k + 1];
+  }
   __syncthreads();
 #pragma unroll
   for (uint32_t k = 0; k < kSpSources / kSpThreads; k++) {
     const uint32_t i = k * kSpThreads + tid;
-    if ((first_of_run >> k) & 1u) items[atomicAdd(&cursor[mixed[k] >> (32 - kSpPosBits)], 1u)] = (mixed[k] << kSpTagShift) | i;
+    if ((first_of_run >> k) & 1u) {
+      const uint32_t hb = mixed[k] >> (32 - kSpPosBits), sh16 = 16 * (hb & 1u);
+      items[(atomicAdd(&cursor2[hb >> 1], 1u << sh16) >> sh16) & 0xffffu] = (mixed[k] << kSpTagShift) | i;
+    }
   }
   __syncthreads();
   // every thread: positions a+tid, a+tid+512, ...
