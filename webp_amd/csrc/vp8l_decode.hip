@@ -1609,26 +1609,45 @@ __device__ __forceinline__ bool pass_transform(const DecResult &r, uint32_t pass
   return true;
 }
 
-// Colour indexing expands bundled indices in place, so the indices are set aside first
-// (the reference copies the whole image, transform.h:62).
-__global__ __launch_bounds__(256) void k_inverse_stash(const DecImage *__restrict__ imgs, const DecResult *__restrict__ res,
-                                                       const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t pass) {
-  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb);
-  XformRec x;
-  if (!pass_transform(res[img], pass, x) || x.type != 3 || x.bits == 0) return;
-  const DecImage im = imgs[img];
-  const uint64_t cnt = (uint64_t)((im.w + (1u << x.bits) - 1) >> x.bits) * im.h;
-  const uint64_t p0 = (uint64_t)(unit - sb_first[img] * kUnitsPerSuper) * kUnit;
-  for (uint32_t k = 0; k < kUnit / 256; k++) {
-    const uint64_t p = p0 + k * 256 + threadIdx.x;
-    if (p < cnt) im.scratch[p] = im.out[p];
+// What the four passes have to do over the whole call: kinds[pass] has kXfStash / kXfPointwise / kXfPredictor set if
+// some image needs that kernel in that pass.  Most calls need one pass (subtract green); the launches of the other
+// passes, a workgroup per 4096 pixels that looks up its image and leaves, took 1.3 ms per gigapixel.
+constexpr uint32_t kXfStash = 1, kXfPointwise = 2, kXfPredictor = 4;
+__global__ __launch_bounds__(256) void k_pass_kinds(const DecResult *__restrict__ res, uint32_t n, uint32_t *__restrict__ kinds) {
+  const uint32_t img = blockIdx.x * 256 + threadIdx.x;
+  if (img >= n) return;
+  for (uint32_t pass = 0; pass < 4; pass++) {
+    XformRec x;
+    if (!pass_transform(res[img], pass, x)) continue;
+    const uint32_t k = x.type == 0 ? kXfPredictor : (x.type == 3 && x.bits != 0 ? (kXfStash | kXfPointwise) : kXfPointwise);
+    if ((kinds[pass] & k) != k) atomicOr(&kinds[pass], k);
   }
 }
 
-__global__ __launch_bounds__(256) void k_inverse_pointwise(const DecImage *__restrict__ imgs, const DecResult *__restrict__ res,
-                                                           const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t pass) {
-  __shared__ uint32_t pal[kMaxPalette];
-  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+// Colour indexing expands bundled indices in place, so the indices are set aside first
+// (the reference copies the whole image, transform.h:62).
+__global__ __launch_bounds__(256) void k_inverse_stash(const DecImage *__restrict__ imgs, const DecResult *__restrict__ res,
+                                                       const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t pass,
+                                                       const uint32_t *__restrict__ kinds, uint32_t units) {
+  if (!(kinds[pass] & kXfStash)) return;
+  for (uint32_t unit = blockIdx.x; unit < units; unit += gridDim.x) {  // the grid is smaller than `units` for the later passes
+    const uint32_t sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb);
+    XformRec x;
+    if (!pass_transform(res[img], pass, x) || x.type != 3 || x.bits == 0) continue;
+    const DecImage im = imgs[img];
+    const uint64_t cnt = (uint64_t)((im.w + (1u << x.bits) - 1) >> x.bits) * im.h;
+    const uint64_t p0 = (uint64_t)(unit - sb_first[img] * kUnitsPerSuper) * kUnit;
+    for (uint32_t k = 0; k < kUnit / 256; k++) {
+      const uint64_t p = p0 + k * 256 + threadIdx.x;
+      if (p < cnt) im.scratch[p] = im.out[p];
+    }
+  }
+}
+
+__device__ __forceinline__ void inverse_pointwise_unit(const DecImage *__restrict__ imgs, const DecResult *__restrict__ res,
+                                                       const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t pass, uint32_t unit,
+                                                       uint32_t *pal) {
+  const uint32_t sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   XformRec x;
   if (!pass_transform(res[img], pass, x) || x.type == 0) return;
   const DecImage im = imgs[img];
@@ -1650,6 +1669,7 @@ __global__ __launch_bounds__(256) void k_inverse_pointwise(const DecImage *__res
     }
   } else {  // transform.h:59-87; only `width` pixels per row are produced (the reference overruns the row)
     const uint32_t ncolors = x.xsize;
+    __syncthreads();  // the unit before this one may still be reading its palette
     if (tid < ncolors) pal[tid] = td[tid];
     __syncthreads();
     const uint32_t bits = x.bits, per = 1u << bits, bpp = 8u >> bits, mask = (1u << bpp) - 1u;
@@ -1664,6 +1684,15 @@ __global__ __launch_bounds__(256) void k_inverse_pointwise(const DecImage *__res
       im.out[p] = c < ncolors ? pal[c] : 0u;  // the reference does not range-check the index (transform.h:82)
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_inverse_pointwise(const DecImage *__restrict__ imgs, const DecResult *__restrict__ res,
+                                                           const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t pass,
+                                                           const uint32_t *__restrict__ kinds, uint32_t units) {
+  __shared__ uint32_t pal[kMaxPalette];
+  if (!(kinds[pass] & kXfPointwise)) return;
+  // the grid is smaller than `units` for the later passes, which most calls do not need
+  for (uint32_t unit = blockIdx.x; unit < units; unit += gridDim.x) inverse_pointwise_unit(imgs, res, sb_first, n, pass, unit, pal);
 }
 
 // Predictor inverse (transform.h:110-191).  Pixel (x,y) needs L, T, TL and TR = (x+1, y-1), so row y
@@ -1884,6 +1913,7 @@ struct vp8l_decoder {
   DeviceBuffer d_imgs, d_res, d_sbfirst, d_aux, d_scratch, d_groups, d_cache, d_sorted;
   DeviceBuffer d_par, d_srcg, d_segmap, d_segidx, d_segfirst, d_lanefirst, d_jumpflags, d_records;  // the segment kernels' workspace
   DeviceBuffer d_progress;  // the banded predictor inverse: pixels finished per band
+  DeviceBuffer d_kinds;     // which inverse-transform kernels each of the four passes needs
   double last_seconds = 0;
   int threads_per_stream = 0;  // 0: chosen per call
   int whole_device = 0;        // 0: chosen per call, 1: never, 2: whenever the stream qualifies
@@ -1933,7 +1963,7 @@ extern "C" void vp8l_decoder_destroy(vp8l_decoder *d) {
   if (d->ev0) (void)hipEventDestroy(d->ev0);
   if (d->ev1) (void)hipEventDestroy(d->ev1);
   DeviceBuffer *bufs[] = {&d->d_imgs, &d->d_res, &d->d_sbfirst, &d->d_aux, &d->d_scratch, &d->d_groups, &d->d_cache, &d->d_sorted,
-                          &d->d_par, &d->d_srcg, &d->d_segmap, &d->d_segidx, &d->d_segfirst, &d->d_lanefirst, &d->d_jumpflags, &d->d_records, &d->d_progress};
+                          &d->d_par, &d->d_srcg, &d->d_segmap, &d->d_segidx, &d->d_segfirst, &d->d_lanefirst, &d->d_jumpflags, &d->d_records, &d->d_progress, &d->d_kinds};
   for (auto *b : bufs) b->release();
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
@@ -1991,7 +2021,7 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
   uint32_t max_bands = 1;
   for (uint32_t k = 0; k < m; k++) max_bands = std::max(max_bands, (height[idx[k]] + kBandRows - 1) / kBandRows);
   const bool ok = d->d_imgs.reserve(m * sizeof(DecImage)) && d->d_res.reserve(m * sizeof(DecResult)) &&
-                  d->d_progress.reserve((size_t)m * max_bands * 4) &&
+                  d->d_progress.reserve((size_t)m * max_bands * 4) && d->d_kinds.reserve(4 * 4) &&
                   d->d_sbfirst.reserve((m + 1) * 4) && d->d_aux.reserve(aux_total * 4) &&
                   d->d_scratch.reserve(scratch_total * 4) &&
                   d->d_groups.reserve((size_t)m * group_cap * sizeof(GroupTables) + 16) &&
@@ -2057,9 +2087,14 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
     hipLaunchKernelGGL(k_par_gather, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m);
     hipLaunchKernelGGL(k_par_finish, dim3(m), dim3(1), 0, s, dimgs, dres);
   }
+  uint32_t *kinds = d->d_kinds.as<uint32_t>();
+  (void)hipMemsetAsync(kinds, 0, 4 * 4, s);
+  hipLaunchKernelGGL(k_pass_kinds, dim3((m + 255) / 256), dim3(256), 0, s, dres, m, kinds);
   for (uint32_t pass = 0; pass < 4; pass++) {
-    hipLaunchKernelGGL(k_inverse_stash, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m, pass);
-    hipLaunchKernelGGL(k_inverse_pointwise, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m, pass);
+    // the first pass has work in nearly every call; a later pass rarely, so it gets a grid that costs little to launch in vain
+    const uint32_t grid = pass == 0 ? gunits : std::min(gunits, 8192u);
+    hipLaunchKernelGGL(k_inverse_stash, dim3(grid), dim3(256), 0, s, dimgs, dres, sbf, m, pass, kinds, gunits);
+    hipLaunchKernelGGL(k_inverse_pointwise, dim3(grid), dim3(256), 0, s, dimgs, dres, sbf, m, pass, kinds, gunits);
     if (pred_bands) {
       (void)hipMemsetAsync(d->d_progress.ptr, 0, (size_t)m * max_bands * 4, s);
       // 36 KiB of LDS nobody uses: at most four of these one-wave workgroups then share a CU (one per SIMD); left to
