@@ -144,7 +144,7 @@ int vp8l_decoder_decode_device(vp8l_decoder *dec, size_t n, const uint8_t *const
 /* VP8L_DEC_OPT_SCOUT_FORM: how a segment's scout finds its tokens.  0 (default) = the segment is cut into pieces of 8192
  * bits, a lane decodes a piece token after token, first from a guessed entry and again from where the lane before it
  * left, until no entry changes; 1 = a token is decoded at every bit offset and the chain is found by pointer jumping
- * (the first version: a quarter faster for a single stream, three to four times slower for batches).  Identical
+ * (the first version: three to five times slower for batches).  Identical
  * pixels and verdicts. */
 enum { VP8L_DEC_OPT_THREADS_PER_STREAM = 1, VP8L_DEC_OPT_WHOLE_DEVICE = 2, VP8L_DEC_OPT_SCOUT_FORM = 3 };
 int vp8l_decoder_set_option(vp8l_decoder *dec, int option, int value);
