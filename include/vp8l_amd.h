@@ -139,7 +139,7 @@ int vp8l_decoder_decode_device(vp8l_decoder *dec, size_t n, const uint8_t *const
  * 3840x2160 stream in 3 ms instead of half a second, 29 GP/s instead of 4.2 for a large batch).  0 (default) = when a
  * call has at least 2 MiB of streams; 1 = never; 2 = always.  Images below 65536 pixels, streams with a colour cache,
  * several Huffman groups or tokens the segment decoder does not take are decoded by one workgroup each as before.
- * Workspace: 16 bytes per stream byte and 4 bytes per pixel, in passes of at most 1 GiB of streams.  Identical pixels
+ * Workspace: 16 bytes per stream byte and 4 bytes per pixel, in passes of at most 2 GiB of streams.  Identical pixels
  * and verdicts. */
 /* VP8L_DEC_OPT_SCOUT_FORM: how a segment's scout finds its tokens.  0 (default) = the segment is cut into pieces of 8192
  * bits, a lane decodes a piece token after token, first from a guessed entry and again from where the lane before it

@@ -2140,7 +2140,7 @@ extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8
   // The segment kernels (streams spread over the device) decode faster than a workgroup per stream for any number of
   // streams (6.7 against 4.2 GP/s photo-like at 256 streams, 3 ms against 500 for one 4K stream); they need enough
   // stream bytes to make segments worth launching, and 16 bytes of token records per stream byte, so a large batch
-  // goes through them in passes of at most 1 GiB of streams.
+  // goes through them in passes of at most 2 GiB of streams.
   if (pending.empty()) return VP8L_OK;
   uint64_t stream_bytes = 0;
   for (uint32_t i : pending) stream_bytes += len[i];
@@ -2153,7 +2153,7 @@ extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8
   struct Todo { std::vector<uint32_t> idx; int mode; uint32_t group_cap; bool pred_bands; };
   std::vector<Todo> todo;
   if (whole_device) {
-    constexpr uint64_t kPassBytes = 1ull << 30;
+    constexpr uint64_t kPassBytes = 2ull << 30;
     std::vector<std::vector<uint32_t>> parts(1);
     uint64_t acc = 0;
     for (uint32_t i : pending) {
@@ -2170,6 +2170,18 @@ extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8
     todo.pop_back();
     std::vector<DecResult> results;
     const int rc = decode_pass(d, t.idx, d_data, len, width, height, d_argb, t.group_cap, t.mode, t.pred_bands, results);
+    if (rc == VP8L_ERR_NO_MEMORY && t.mode != 0) {
+      // no room for the segment kernels' workspace: half the streams at a time, a single stream by one workgroup
+      (void)hipGetLastError();  // the failed allocation is dealt with here; the next pass checks for launch errors
+      if (t.idx.size() > 1) {
+        const size_t half = t.idx.size() / 2;
+        todo.push_back({std::vector<uint32_t>(t.idx.begin() + half, t.idx.end()), t.mode, t.group_cap, t.pred_bands});
+        todo.push_back({std::vector<uint32_t>(t.idx.begin(), t.idx.begin() + half), t.mode, t.group_cap, t.pred_bands});
+      } else {
+        todo.push_back({t.idx, 0, t.group_cap, t.pred_bands});
+      }
+      continue;
+    }
     if (rc != VP8L_OK) return rc;
     Todo more_groups{{}, t.mode, t.group_cap, t.pred_bands}, with_maps{{}, 2, t.group_cap, t.pred_bands}, one_workgroup{{}, 0, t.group_cap, t.pred_bands},
         one_block_predictor{{}, t.mode, t.group_cap, false};
