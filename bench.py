@@ -138,7 +138,7 @@ def workload_decode1080p(args, world, rank, local_rank, dev):
                      "batch of %d synthetic %dx%d streams per rank (half photo-like, half graphics), VP8L decode "
                      "(BASELINE configs[3] = 4096 streams over 8 GPUs); streams and pixels resident in HBM" % (batch, w, h),
                      {"bits_per_pixel": bpp, "roundtrip_verified": ok, "device_ms_per_step": 1e3 * dev_s,
-                      "roofline": {"kernel": "whole decode path (k_par_scout_lanes, k_par_place, k_par_jump, k_par_gather, inverse transforms) over the end-to-end algorithmic bytes", "bound": "hbm",
+                      "roofline": {"kernel": "whole decode path (k_par_scout_lanes, k_par_place, k_par_jump, inverse transforms) over the end-to-end algorithmic bytes", "bound": "hbm",
                                    "achieved": alg / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dev_s / 1e9 / HBM_PEAK_GBS,
                                    "traffic": None, "algorithmic_bytes_per_launch": alg}})
     out["cpu_baseline"] = None

@@ -782,8 +782,8 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, const VP8L
 //                 segment (one table lookup per segment).
 //   k_par_pixels  per segment again, now knowing where to start: tokens -> literals into the image, and for
 //                 every pixel a reference makes the position its value comes from.
-//   k_par_jump    pointer jumping over all pixels until every pixel points at a literal (log2 of the longest
-//                 chain of references passes); k_par_gather fetches the values.
+//   k_par_jump    pointer jumping over all pixels until every pixel points at a literal (log4 of the longest
+//                 chain of references passes); a pixel takes its value in the pass that finds its literal.
 // A token the span decoder cannot take (longer than 64 bits, zero bits, a reference longer than 255), or a
 // stream that ends early, sends the stream back to the one-workgroup form (status kParFallback).
 // =============================================================================================
@@ -1466,7 +1466,7 @@ __global__ __launch_bounds__(256) void k_par_jump(const DecImage *__restrict__ i
     if (!par || !par->active || par->status != kOk) continue;
     if (pass > 0 && !par->changed[pass - 1]) continue;  // the pass before left nothing open
     const uint64_t p0 = (uint64_t)(unit - sb_first[img] * kUnitsPerSuper) * kUnit;
-    uint32_t *srcg = par->srcg;
+    uint32_t *srcg = par->srcg, *dst = par->dst;
     const uint32_t total = par->total;
     bool open = false;
     for (uint32_t k = 0; k < kUnit / 256; k++) {
@@ -1480,34 +1480,14 @@ __global__ __launch_bounds__(256) void k_par_jump(const DecImage *__restrict__ i
           if (!(t & kFinalBit)) t = __hip_atomic_load(&srcg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (!(t & kFinalBit)) t = __hip_atomic_load(&srcg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&srcg[p], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          open = open || !(t & kFinalBit);
+          // a chain that has reached its literal (whose pixel the kernels before this one wrote) gives the pixel its value
+          // here, once: the position is final from now on and no pass looks at it again
+          if (t & kFinalBit) dst[p] = dst[t & ~kFinalBit];
+          else open = true;
         }
       }
     }
     if (__syncthreads_or(open) && threadIdx.x == 0) { par->changed[pass] = 1; any_open[pass] = 1; }
-  }
-}
-
-__global__ __launch_bounds__(256) void k_par_gather(const DecImage *__restrict__ imgs, DecResult *__restrict__ res, const uint32_t *__restrict__ sb_first,
-                                                    uint32_t n) {
-  const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb);
-  ParImage *par = imgs[img].par;
-  if (!par || !par->active) return;
-  const uint64_t p0 = (uint64_t)(unit - sb_first[img] * kUnitsPerSuper) * kUnit;
-  // a chain of references longer than 2^32 passes cannot exist; one still open here means the passes were cut short
-  int32_t status = par->status;
-  if (status == kOk && par->changed[kParJumpPasses - 1]) status = kParFallback;
-  if (status == kOk) {
-    uint32_t *dst = par->dst;
-    const uint32_t *srcg = par->srcg;
-    const uint32_t total = par->total;
-    for (uint32_t k = 0; k < kUnit / 256; k++) {
-      const uint64_t p = p0 + k * 256 + threadIdx.x;
-      if (p < total) {
-        const uint32_t s = srcg[p] & ~kFinalBit;
-        if (s != p) dst[p] = dst[s];  // s is a literal's position: written by k_par_pixels, never by this kernel
-      }
-    }
   }
 }
 
@@ -2084,7 +2064,6 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
     }
     for (uint32_t pass = 0; pass < kParJumpPasses; pass++)
       hipLaunchKernelGGL(k_par_jump, dim3(std::min(gunits, kParJumpGrid)), dim3(256), 0, s, dimgs, sbf, m, pass, gunits, d->d_jumpflags.as<uint32_t>());
-    hipLaunchKernelGGL(k_par_gather, dim3(gunits), dim3(256), 0, s, dimgs, dres, sbf, m);
     hipLaunchKernelGGL(k_par_finish, dim3(m), dim3(1), 0, s, dimgs, dres);
   }
   uint32_t *kinds = d->d_kinds.as<uint32_t>();
