@@ -771,9 +771,16 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, const VP8L
 
 
 // =============================================================================================
-// One large stream decoded by the whole device.
-// A workgroup decodes a stream at the rate of one CU.  For a few large streams the main image is cut
-// into segments of 64 spans (65536 stream bits) that are decoded by as many workgroups:
+// Streams decoded by the whole device.
+// A workgroup decodes a stream at the rate of one CU.  Here the main image's part of a stream is cut into
+// segments of 65536 stream bits, and three sets of kernels find the tokens of all segments at once.
+// Tried first (mode 1), both ending in k_par_verify (a serial check per stream that every segment was entered
+// where the one before it was left) and k_par_place (token records -> literals and reference sources):
+//   k_par_scout_lanes  a lane per piece of 8192 bits decodes token after token; entries are handed from lane to
+//                      lane until they settle (the default)
+//   k_par_scout        a workgroup per segment decodes a token at every bit offset and follows the chain after a
+//                      warm-up of 4096 bits (the first version, VP8L_DEC_OPT_SCOUT_FORM = 1)
+// For a stream whose scouts were not in step (mode 2), exact for any stream at twice the token decoding:
 //   k_par_maps    per segment and for each of the 64 bit offsets at which the token chain can enter it (a
 //                 token is at most 64 bits long): where the chain leaves the segment and how many pixels it
 //                 makes on the way.  Per span this is pointer jumping over (next offset, exit, pixels) for all
