@@ -1409,8 +1409,8 @@ __global__ __launch_bounds__(kPlaceThreads) void k_par_place(const DecImage *__r
   for (uint32_t j = 0; j < kLanesPerSeg; j++) before_part[j] = parts ? (uint32_t)slot[4 + j] : 0u;
   uint32_t *dst = par->dst, *srcg = par->srcg;
   bool bad = false;
-  for (uint32_t t0 = 0; t0 < ntok && fill < total; t0 += kPlaceThreads) {
-    const uint32_t i = t0 + tid;
+  auto record = [&](uint32_t i) -> uint64_t {  // token i of the segment
+    if (i >= ntok) return 0ull;
     uint32_t at = i;
     if (parts) {
       uint32_t part = 0;
@@ -1421,7 +1421,12 @@ __global__ __launch_bounds__(kPlaceThreads) void k_par_place(const DecImage *__r
       for (uint32_t j = 1; j < kLanesPerSeg; j++) b4 = part == j ? before_part[j] : b4;
       at = part * kLaneRecCap + (i - b4);
     }
-    const uint64_t rc = i < ntok ? rec[at] : 0ull;
+    return rec[at];
+  };
+  uint64_t rc_next = record(tid);
+  for (uint32_t t0 = 0; t0 < ntok && fill < total; t0 += kPlaceThreads) {
+    const uint64_t rc = rc_next;
+    rc_next = record(t0 + kPlaceThreads + tid);  // on its way while this round's tokens are placed
     const uint32_t val = (uint32_t)rc, cnt = (uint32_t)(rc >> 32) & 0xffu;
     const bool ref = (rc >> 40) & 1ull;
     const uint32_t incl = wave_incl_scan_u32(cnt, (int)lane);
