@@ -95,6 +95,25 @@ int vp8l_encoder_encode_device(vp8l_encoder *enc, size_t n, const uint32_t *cons
                                const uint32_t *height, uint8_t *d_out, size_t out_cap, size_t *out_offset,
                                size_t *out_len, int *status);
 
+/* ---- one image, device memory, no allocation ------------------------------------------------
+ * No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  The same kernels and the same bytes as
+ * vp8l_encoder_encode_device with one image and default options, but the workspace is a static array in device memory
+ * (about 20 MB, held by every GPU the library runs on until the process ends) instead of a context's hipMalloc'ed
+ * buffers, and the call makes no hipMalloc / hipFree / host allocation.  At most VP8L_NOALLOC_MAX_PIXELS pixels
+ * (1920x1080 fits); larger images return VP8L_ERR_NO_MEMORY.
+ *   device    < 0 = the current device
+ *   stream    a hipStream_t (NULL = the null stream); every kernel of the call is launched on it
+ *   d_out     device buffer, 256-byte aligned, out_cap >= vp8l_encode_bound(width, height)
+ *   d_result  optional device pointer to two uint64: [0] = status (a vp8l_status, sign-extended), [1] = stream bytes
+ *   out_len   optional host pointer.  Non-NULL: the call waits for the stream and returns the image's status with
+ *             *out_len set.  NULL: nothing is waited for (the call only launches) and VP8L_OK means "launched".
+ * The address of the static array is looked up once per device, by vp8l_init() or else by the first call on the device.
+ * All calls on one GPU share the array: calls that overlap in time on one GPU (two streams, two threads) race. */
+#define VP8L_NOALLOC_MAX_PIXELS (1u << 21)
+int vp8l_encode_device_noalloc(int device, void *stream, const uint32_t *d_argb, uint32_t width, uint32_t height,
+                               uint8_t *d_out, size_t out_cap, uint64_t *d_result, size_t *out_len);
+
 /* Options.  VP8L_OPT_MATCH_SEARCH: 0 (default) = candidate-list match search with the exhaustive
  * search as fallback for tiles with heavy duplication; 1 = exhaustive search everywhere.  Both give
  * identical streams; the option exists for verification and measurement. */

@@ -99,6 +99,8 @@ def lib():
         L.vp8l_decoder_last_scout_streams.argtypes = [C.c_void_p]
         L.vp8l_decoder_last_scout_streams.restype = C.c_long
         L.vp8l_generate_device.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.vp8l_encode_device_noalloc.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
+                                                 C.c_void_p, C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
 
@@ -111,7 +113,7 @@ EXPORTED_SYMBOLS = (
     "vp8l_decoder_last_device_seconds", "vp8l_generate_device", "vp8l_encoder_set_option",
     "vp8l_encoder_last_dense_tiles", "vp8l_decoder_set_option",
     "vp8l_decoder_last_whole_device_streams",
-    "vp8l_decoder_last_scout_streams",
+    "vp8l_decoder_last_scout_streams", "vp8l_encode_device_noalloc",
 )
 
 
@@ -371,3 +373,17 @@ def generate_device(mode, w, h, seed, ncolors, d_ptr, device=-1):
     rc = lib().vp8l_generate_device(device, mode, w, h, seed, ncolors, d_ptr)
     if rc != OK:
         raise Vp8lError(rc, "vp8l_generate_device")
+
+
+NOALLOC_MAX_PIXELS = 1 << 21
+
+
+def encode_device_noalloc(d_argb_ptr, width, height, d_out_ptr, out_cap, device=-1, stream=None, d_result_ptr=None, wait=True):
+    """vp8l_encode_device_noalloc: one image, workspace in a static device array, no allocation.  Returns the stream
+    length (wait=True) or None (wait=False: read the two uint64 at d_result_ptr after synchronising yourself)."""
+    n = C.c_size_t()
+    rc = lib().vp8l_encode_device_noalloc(device, stream, d_argb_ptr, width, height, d_out_ptr, out_cap, d_result_ptr,
+                                          C.byref(n) if wait else None)
+    if rc != OK:
+        raise Vp8lError(rc, "vp8l_encode_device_noalloc")
+    return n.value if wait else None

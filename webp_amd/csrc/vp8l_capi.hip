@@ -257,6 +257,7 @@ extern "C" int vp8l_init(void) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::string(prop.gcnArchName).rfind("gfx950", 0) == 0) usable++;
   }
+  if (usable > 0) noalloc_setup_all_devices();
   return usable > 0 ? usable : VP8L_ERR_NO_DEVICE;
 }
 

@@ -1538,6 +1538,76 @@ struct vp8l_encoder {
   double stage_seconds[9] = {};
 };
 
+// The device arrays one encode call works in (a context's grow-only workspace, or parts of the static scratch array).
+struct EncBuffers {
+  EncImage *imgs;
+  EncState *st;
+  uint32_t *sbf;
+  unsigned long long *gsets;
+  uint32_t *pix_t;  // output of the pixel transform
+  uint32_t *pix;    // what the match search and the coder read (pix_t unless a predictor / cross-colour pass follows)
+  uint32_t *modes, *elems;
+  uint32_t *match, *flags, *histo;
+  CodeTables *tables;
+  uint8_t *sx, *entry;
+  uint32_t *ubits;
+  uint64_t *uoff;
+  uint8_t *dense;
+  uint16_t *gbits;
+  uint8_t *adv8;
+};
+
+// Clears what must start at zero and launches every kernel of the encode path for nl images that occupy sb_total
+// superblocks; imgs and sbf are already on their way on the same stream.  ev: ten events for stage times, or null.
+static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl, uint32_t sb_total, uint32_t pred, uint32_t cross,
+                                 int match_mode, uint8_t *d_out, hipEvent_t *ev) {
+  bool h = true;
+  h = h && hip_ok(hipMemsetAsync(B.st, 0, nl * sizeof(EncState), s), "clear state");
+  h = h && hip_ok(hipMemsetAsync(B.gsets, 0xff, (size_t)nl * kSetSlots * sizeof(unsigned long long), s), "clear sets");
+  h = h && hip_ok(hipMemsetAsync(B.histo, 0, (size_t)nl * kNumCodes * kCodeStride * 4, s), "clear histograms");
+  h = h && hip_ok(hipMemsetAsync(B.dense, 0, (size_t)sb_total * (kSuper / kLzTile), s), "clear tile flags");
+  if (!h) return VP8L_ERR_HIP;
+  auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], s); };
+  const uint32_t gsb = sb_total, gunits = sb_total * kUnitsPerSuper;
+  mark(0);
+  hipLaunchKernelGGL(k_palette_scan, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.gsets);
+  hipLaunchKernelGGL(k_palette_finalize, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.gsets, (match_mode == 0 && !pred && !cross) ? 1u : 0u, pred, cross);
+  mark(1);
+  hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix_t);
+  if (pred) {
+    hipLaunchKernelGGL(k_pred_modes, dim3(nl * kSmallMax), dim3(256), 0, s, B.imgs, B.st, B.pix_t, B.modes);
+    hipLaunchKernelGGL(k_pred_residual, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix_t, B.modes, B.pix);
+  }
+  if (cross) {  // on what the predictor left (in place), or on the subtract-green image
+    const uint32_t *from = pred ? B.pix : B.pix_t;
+    hipLaunchKernelGGL(k_cross_elems, dim3(nl * kSmallMax), dim3(64), 0, s, B.imgs, B.st, from, B.elems);
+    hipLaunchKernelGGL(k_cross_apply, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, from, B.elems, B.pix);
+  }
+  mark(2);
+  if (match_mode == 0)
+    hipLaunchKernelGGL(k_lz77_sparse, dim3((gsb * (kSuper / kSpTile) + 7) / 8 * 8), dim3(kSpThreads), 0, s, B.imgs, B.st, B.sbf, nl,
+                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense);
+  mark(9);  // also when the candidate-list kernel is switched off
+  hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,
+                     match_mode == 0 ? B.dense : (const uint8_t *)nullptr);
+  mark(3);
+  hipLaunchKernelGGL(k_parse_exits, dim3(gsb), dim3(128), 0, s, B.imgs, B.st, B.sbf, nl, B.adv8, B.sx);
+  hipLaunchKernelGGL(k_parse_chain, dim3(nl), dim3(256), 0, s, B.st, B.sbf, B.sx, B.entry);
+  hipLaunchKernelGGL(k_parse_mark, dim3(gsb), dim3(128), 0, s, B.imgs, B.st, B.sbf, nl, B.adv8, B.entry, B.flags);
+  mark(4);
+  hipLaunchKernelGGL(k_histogram, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.histo);
+  mark(5);
+  hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.histo, B.tables, B.modes, B.elems, d_out);
+  mark(6);
+  hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables, B.gbits, B.ubits);
+  hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.sbf, B.ubits, B.uoff, d_out);
+  mark(7);
+  hipLaunchKernelGGL(k_emit, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables, B.gbits, B.uoff, d_out);
+  mark(8);
+  if (!hip_ok(hipGetLastError(), "kernel launch")) return VP8L_ERR_HIP;
+  return VP8L_OK;
+}
+
 extern "C" size_t vp8l_encode_bound(uint32_t w, uint32_t h) {
   // a Huffman code never spends more than a fixed-length code would: <= 9+8+8+8 bits per literal,
   // <= 9+5+6+9 per match, at most one token per pixel; plus headers and the palette sub-image
@@ -1615,6 +1685,7 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
     out_offset[i] = (size_t)im.out_off;
   }
   e->sb_first[nl] = (uint32_t)sb_total;
+  int rc_launch = VP8L_OK;
   const uint64_t npos = sb_total * kSuper;
   const uint64_t nunits = sb_total * kUnitsPerSuper;
 
@@ -1632,73 +1703,36 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
   if (!ok) return VP8L_ERR_NO_MEMORY;
 
   hipStream_t s = e->stream;
-  auto *imgs = e->d_imgs.as<EncImage>();
-  auto *st = e->d_state.as<EncState>();
-  auto *sbf = e->d_sbfirst.as<uint32_t>();
-  auto *gsets = e->d_gsets.as<unsigned long long>();
-  auto *pix_t = e->d_pix.as<uint32_t>();                          // output of the pixel transform
   const uint32_t pred = (uint32_t)e->pred_bits, cross = (uint32_t)e->cross_bits;
-  auto *pix = (pred || cross) ? e->d_pix2.as<uint32_t>() : pix_t;  // what the match search and the coder read
-  auto *modes = (pred || cross) ? e->d_modes.as<uint32_t>() : nullptr;
-  auto *elems = (pred || cross) ? e->d_elems.as<uint32_t>() : nullptr;
-  auto *match = e->d_match.as<uint32_t>();
-  auto *flags = e->d_flags.as<uint32_t>();
-  auto *histo = e->d_histo.as<uint32_t>();
-  auto *tables = e->d_tables.as<CodeTables>();
-  auto *sx = e->d_sx.as<uint8_t>();
-  auto *entry = e->d_entry.as<uint8_t>();
-  auto *ubits = e->d_unit_bits.as<uint32_t>();
-  auto *uoff = e->d_unit_off.as<uint64_t>();
-  auto *dense = e->d_dense.as<uint8_t>();
-  auto *gbits = e->d_group_bits.as<uint16_t>();
-  auto *adv8 = e->d_adv.as<uint8_t>();
+  EncBuffers B;
+  B.imgs = e->d_imgs.as<EncImage>();
+  B.st = e->d_state.as<EncState>();
+  B.sbf = e->d_sbfirst.as<uint32_t>();
+  B.gsets = e->d_gsets.as<unsigned long long>();
+  B.pix_t = e->d_pix.as<uint32_t>();
+  B.pix = (pred || cross) ? e->d_pix2.as<uint32_t>() : B.pix_t;
+  B.modes = (pred || cross) ? e->d_modes.as<uint32_t>() : nullptr;
+  B.elems = (pred || cross) ? e->d_elems.as<uint32_t>() : nullptr;
+  B.match = e->d_match.as<uint32_t>();
+  B.flags = e->d_flags.as<uint32_t>();
+  B.histo = e->d_histo.as<uint32_t>();
+  B.tables = e->d_tables.as<CodeTables>();
+  B.sx = e->d_sx.as<uint8_t>();
+  B.entry = e->d_entry.as<uint8_t>();
+  B.ubits = e->d_unit_bits.as<uint32_t>();
+  B.uoff = e->d_unit_off.as<uint64_t>();
+  B.dense = e->d_dense.as<uint8_t>();
+  B.gbits = e->d_group_bits.as<uint16_t>();
+  B.adv8 = e->d_adv.as<uint8_t>();
+  auto *st = B.st;
+  auto *pix = B.pix;
 
   bool h = true;
-  h = h && hip_ok(hipMemcpyAsync(imgs, e->imgs.data(), nl * sizeof(EncImage), hipMemcpyHostToDevice, s), "upload images");
-  h = h && hip_ok(hipMemcpyAsync(sbf, e->sb_first.data(), (nl + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s), "upload table");
-  h = h && hip_ok(hipMemsetAsync(st, 0, nl * sizeof(EncState), s), "clear state");
-  h = h && hip_ok(hipMemsetAsync(gsets, 0xff, (size_t)nl * kSetSlots * sizeof(unsigned long long), s), "clear sets");
-  h = h && hip_ok(hipMemsetAsync(histo, 0, (size_t)nl * kNumCodes * kCodeStride * 4, s), "clear histograms");
-  h = h && hip_ok(hipMemsetAsync(dense, 0, sb_total * (kSuper / kLzTile), s), "clear tile flags");
+  h = h && hip_ok(hipMemcpyAsync(B.imgs, e->imgs.data(), nl * sizeof(EncImage), hipMemcpyHostToDevice, s), "upload images");
+  h = h && hip_ok(hipMemcpyAsync(B.sbf, e->sb_first.data(), (nl + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s), "upload table");
   if (!h) return VP8L_ERR_HIP;
-
-  const uint32_t gsb = (uint32_t)sb_total, gunits = (uint32_t)nunits;
-  (void)hipEventRecord(e->ev[0], s);
-  hipLaunchKernelGGL(k_palette_scan, dim3(gsb), dim3(256), 0, s, imgs, st, sbf, nl, gsets);
-  hipLaunchKernelGGL(k_palette_finalize, dim3(nl), dim3(256), 0, s, imgs, st, gsets, (e->match_mode == 0 && !pred && !cross) ? 1u : 0u, pred, cross);
-  (void)hipEventRecord(e->ev[1], s);
-  hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix_t);
-  if (pred) {
-    hipLaunchKernelGGL(k_pred_modes, dim3(nl * kSmallMax), dim3(256), 0, s, imgs, st, pix_t, modes);
-    hipLaunchKernelGGL(k_pred_residual, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix_t, modes, pix);
-  }
-  if (cross) {  // on what the predictor left (in place), or on the subtract-green image
-    const uint32_t *from = pred ? pix : pix_t;
-    hipLaunchKernelGGL(k_cross_elems, dim3(nl * kSmallMax), dim3(64), 0, s, imgs, st, from, elems);
-    hipLaunchKernelGGL(k_cross_apply, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, from, elems, pix);
-  }
-  (void)hipEventRecord(e->ev[2], s);
-  if (e->match_mode == 0)
-    hipLaunchKernelGGL(k_lz77_sparse, dim3((gsb * (kSuper / kSpTile) + 7) / 8 * 8), dim3(kSpThreads), 0, s, imgs, st, sbf, nl,
-                       gsb * (kSuper / kSpTile), pix, match, adv8, dense);
-  (void)hipEventRecord(e->ev[9], s);  // also when the candidate-list kernel is switched off
-  hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, adv8,
-                     e->match_mode == 0 ? dense : (const uint8_t *)nullptr);
-  (void)hipEventRecord(e->ev[3], s);
-  hipLaunchKernelGGL(k_parse_exits, dim3(gsb), dim3(128), 0, s, imgs, st, sbf, nl, adv8, sx);
-  hipLaunchKernelGGL(k_parse_chain, dim3(nl), dim3(256), 0, s, st, sbf, sx, entry);
-  hipLaunchKernelGGL(k_parse_mark, dim3(gsb), dim3(128), 0, s, imgs, st, sbf, nl, adv8, entry, flags);
-  (void)hipEventRecord(e->ev[4], s);
-  hipLaunchKernelGGL(k_histogram, dim3(gsb), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, histo);
-  (void)hipEventRecord(e->ev[5], s);
-  hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, imgs, st, histo, tables, modes, elems, d_out);
-  (void)hipEventRecord(e->ev[6], s);
-  hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, gbits, ubits);
-  hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, imgs, st, sbf, ubits, uoff, d_out);
-  (void)hipEventRecord(e->ev[7], s);
-  hipLaunchKernelGGL(k_emit, dim3(gsb), dim3(256), 0, s, imgs, st, sbf, nl, pix, match, flags, tables, gbits, uoff, d_out);
-  (void)hipEventRecord(e->ev[8], s);
-  if (!hip_ok(hipGetLastError(), "kernel launch")) return VP8L_ERR_HIP;
+  rc_launch = launch_encode_kernels(s, B, nl, (uint32_t)sb_total, pred, cross, e->match_mode, d_out, e->ev);
+  if (rc_launch != VP8L_OK) return rc_launch;
   if (!hip_ok(hipMemcpyAsync(e->states.data(), st, nl * sizeof(EncState), hipMemcpyDeviceToHost, s), "download state")) return VP8L_ERR_HIP;
   if (!hip_ok(hipStreamSynchronize(s), "encode batch")) return VP8L_ERR_HIP;
 
@@ -1836,4 +1870,156 @@ extern "C" int vp8l_generate_device(int device, int mode, uint32_t w, uint32_t h
   if (!hip_ok(hipGetLastError(), "k_generate")) return VP8L_ERR_HIP;
   if (!hip_ok(hipDeviceSynchronize(), "k_generate")) return VP8L_ERR_HIP;
   return VP8L_OK;
+}
+
+// =============================================================================================
+// One image with no allocation at all: the encode path's workspace lives in a static device array.
+// For callers that cannot call hipMalloc (code under HIP graph capture, serving loops, harnesses that forbid it).
+// Every GPU the library runs on holds its own copy of the array (at its own address) until the process ends; calls
+// that overlap on one GPU would share it and race.
+// =============================================================================================
+namespace vp8l {
+namespace {
+constexpr uint64_t kNaMaxPixels = VP8L_NOALLOC_MAX_PIXELS;
+constexpr uint64_t kNaSuper = (kNaMaxPixels + kTailPad + kSuper - 1) / kSuper;  // superblocks of the largest image
+constexpr uint64_t kNaPos = kNaSuper * kSuper;
+constexpr uint64_t na_align(uint64_t v) { return (v + 255) & ~(uint64_t)255; }
+// offsets of the parts, each 256-byte aligned
+constexpr uint64_t kNaImgs = 0;
+constexpr uint64_t kNaState = kNaImgs + na_align(sizeof(EncImage));
+constexpr uint64_t kNaSbf = kNaState + na_align(sizeof(EncState));
+constexpr uint64_t kNaResult = kNaSbf + na_align(2 * sizeof(uint32_t));
+constexpr uint64_t kNaGsets = kNaResult + na_align(2 * sizeof(uint64_t));
+constexpr uint64_t kNaHisto = kNaGsets + na_align(kSetSlots * sizeof(unsigned long long));
+constexpr uint64_t kNaTables = kNaHisto + na_align(kNumCodes * kCodeStride * 4);
+constexpr uint64_t kNaSx = kNaTables + na_align(sizeof(CodeTables));
+constexpr uint64_t kNaEntry = kNaSx + na_align(kNaSuper * kBlockLen);
+constexpr uint64_t kNaUbits = kNaEntry + na_align(kNaSuper);
+constexpr uint64_t kNaUoff = kNaUbits + na_align(kNaSuper * kUnitsPerSuper * 4);
+constexpr uint64_t kNaDense = kNaUoff + na_align(kNaSuper * kUnitsPerSuper * 8);
+constexpr uint64_t kNaGbits = kNaDense + na_align(kNaSuper * (kSuper / kLzTile));
+constexpr uint64_t kNaFlags = kNaGbits + na_align(kNaPos / 16 * 2);
+constexpr uint64_t kNaAdv = kNaFlags + na_align(kNaPos / 8);
+constexpr uint64_t kNaPix = kNaAdv + na_align(kNaPos);
+constexpr uint64_t kNaMatch = kNaPix + na_align(kNaPos * 4);
+constexpr uint64_t kNaBytes = kNaMatch + na_align(kNaPos * 4);
+static_assert(kNaBytes < (24u << 20), "the static workspace stays modest");
+}  // namespace
+
+// In host code this name is only a handle for hipGetSymbolAddress: the memory is reached through the per-device
+// address that call returns, never through the name.
+static __device__ __align__(256) uint8_t scratch[kNaBytes];
+
+namespace {
+constexpr int kNaMaxDevices = 64;
+uint8_t *g_na_ptr[kNaMaxDevices] = {};  // address of `scratch` on each device, 0 = not asked yet
+std::mutex g_na_mu;
+
+// Address of the static workspace on `device` (which must be the current device); asked once per device.
+int noalloc_workspace(int device, uint8_t **out) {
+  if (device < 0 || device >= kNaMaxDevices) return VP8L_ERR_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lock(g_na_mu);
+  if (!g_na_ptr[device]) {
+    hipDeviceProp_t prop;
+    if (!hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) return VP8L_ERR_NO_DEVICE;
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+      last_error_slot() = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+      return VP8L_ERR_NO_DEVICE;
+    }
+    void *p = nullptr;
+    if (!hip_ok(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)") || !p) return VP8L_ERR_HIP;
+    g_na_ptr[device] = static_cast<uint8_t *>(p);
+  }
+  *out = g_na_ptr[device];
+  return VP8L_OK;
+}
+}  // namespace
+
+// Called by vp8l_init(): looks the workspace address up on every usable device so that the entry point's first call
+// on a device does nothing but launch.  Leaves the current device as it was.
+void noalloc_setup_all_devices() {
+  int count = 0, before = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || hipGetDevice(&before) != hipSuccess) { (void)hipGetLastError(); return; }
+  for (int d = 0; d < count && d < kNaMaxDevices; d++) {
+    if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
+    uint8_t *p = nullptr;
+    (void)noalloc_workspace(d, &p);
+  }
+  (void)hipSetDevice(before);
+}
+
+// Writes the one-image tables a batch call uploads from the host.
+__global__ void k_noalloc_setup(EncImage *imgs, uint32_t *sbf, const uint32_t *argb, uint32_t w, uint32_t h, uint64_t out_cap,
+                                uint32_t sb_total) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    EncImage im;
+    im.argb = argb; im.w = w; im.h = h; im.pos0 = 0; im.out_off = 0; im.out_cap = out_cap;
+    imgs[0] = im;
+    sbf[0] = 0;
+    sbf[1] = sb_total;
+  }
+}
+
+// result[0] = status (a vp8l_status, sign-extended), result[1] = stream bytes
+__global__ void k_noalloc_result(const EncState *st, uint64_t *result, uint64_t *result2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const uint64_t s = (uint64_t)(int64_t)st[0].status, len = st[0].status == 0 ? (st[0].total_bits + 7) / 8 : 0;
+    result[0] = s; result[1] = len;
+    if (result2) { result2[0] = s; result2[1] = len; }
+  }
+}
+}  // namespace vp8l
+
+extern "C" int vp8l_encode_device_noalloc(int device, void *stream, const uint32_t *d_argb, uint32_t width, uint32_t height,
+                                          uint8_t *d_out, size_t out_cap, uint64_t *d_result, size_t *out_len) {
+  if (out_len) *out_len = 0;
+  if (!d_out || ((uintptr_t)d_out & 255) != 0) return VP8L_ERR_BAD_ARGUMENT;
+  if (!d_argb || width == 0 || height == 0) return VP8L_ERR_INVALID_ARGB;         // vp8l.h:587-588
+  if (width > kMaxDim || height > kMaxDim) return VP8L_ERR_TOO_BIG_ARGB;          // vp8l.h:589-590
+  const uint64_t px = (uint64_t)width * height;
+  if (px > kNaMaxPixels) {
+    last_error_slot() = "vp8l_encode_device_noalloc takes at most VP8L_NOALLOC_MAX_PIXELS pixels";
+    return VP8L_ERR_NO_MEMORY;
+  }
+  if (out_cap < vp8l_encode_bound(width, height)) return VP8L_ERR_NO_MEMORY;
+  if (device < 0) {
+    if (!hip_ok(hipGetDevice(&device), "hipGetDevice")) return VP8L_ERR_NO_DEVICE;
+  } else if (!hip_ok(hipSetDevice(device), "hipSetDevice")) {
+    return VP8L_ERR_NO_DEVICE;
+  }
+  uint8_t *ws = nullptr;
+  int rc = noalloc_workspace(device, &ws);
+  if (rc != VP8L_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  EncBuffers B;
+  B.imgs = reinterpret_cast<EncImage *>(ws + kNaImgs);
+  B.st = reinterpret_cast<EncState *>(ws + kNaState);
+  B.sbf = reinterpret_cast<uint32_t *>(ws + kNaSbf);
+  B.gsets = reinterpret_cast<unsigned long long *>(ws + kNaGsets);
+  B.pix_t = B.pix = reinterpret_cast<uint32_t *>(ws + kNaPix);
+  B.modes = B.elems = nullptr;
+  B.match = reinterpret_cast<uint32_t *>(ws + kNaMatch);
+  B.flags = reinterpret_cast<uint32_t *>(ws + kNaFlags);
+  B.histo = reinterpret_cast<uint32_t *>(ws + kNaHisto);
+  B.tables = reinterpret_cast<CodeTables *>(ws + kNaTables);
+  B.sx = ws + kNaSx;
+  B.entry = ws + kNaEntry;
+  B.ubits = reinterpret_cast<uint32_t *>(ws + kNaUbits);
+  B.uoff = reinterpret_cast<uint64_t *>(ws + kNaUoff);
+  B.dense = ws + kNaDense;
+  B.gbits = reinterpret_cast<uint16_t *>(ws + kNaGbits);
+  B.adv8 = ws + kNaAdv;
+  uint64_t *result = reinterpret_cast<uint64_t *>(ws + kNaResult);
+  const uint32_t sb_total = (uint32_t)((px + kTailPad + kSuper - 1) / kSuper);
+  hipLaunchKernelGGL(k_noalloc_setup, dim3(1), dim3(64), 0, s, B.imgs, B.sbf, d_argb, width, height, (uint64_t)vp8l_encode_bound(width, height), sb_total);
+  rc = launch_encode_kernels(s, B, 1, sb_total, 0, 0, 0, d_out, nullptr);
+  if (rc != VP8L_OK) return rc;
+  hipLaunchKernelGGL(k_noalloc_result, dim3(1), dim3(64), 0, s, B.st, result, d_result);
+  if (!hip_ok(hipGetLastError(), "kernel launch")) return VP8L_ERR_HIP;
+  if (!out_len) return VP8L_OK;  // the caller reads d_result behind its own synchronisation
+  uint64_t host_result[2] = {0, 0};
+  if (!hip_ok(hipMemcpyAsync(host_result, result, sizeof(host_result), hipMemcpyDeviceToHost, s), "download result")) return VP8L_ERR_HIP;
+  if (!hip_ok(hipStreamSynchronize(s), "encode (no allocation)")) return VP8L_ERR_HIP;
+  *out_len = (size_t)host_result[1];
+  return (int)(int64_t)host_result[0];
 }

@@ -20,6 +20,9 @@ bool hip_ok(hipError_t e, const char *what);
 // device < 0 keeps the current device.  Fails with VP8L_ERR_NO_DEVICE when no gfx950 is usable.
 int select_device(int device, int *chosen);
 
+// Looks up the address of the static no-allocation workspace on every device (vp8l_encode.hip).
+void noalloc_setup_all_devices();
+
 // Grow-only device allocation (the contexts keep their workspace between calls).
 struct DeviceBuffer {
   void *ptr = nullptr;
