@@ -18,6 +18,7 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -88,6 +89,10 @@ inline Image read_png_bytes(const std::vector<uint8_t> &file) {
       if (len < 13) throw Error{"PNG: bad IHDR"};
       w = be32(data); h = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12];
       have_ihdr = true;
+      // Nothing is sized by the header's untrusted numbers beyond what the encoder accepts (vp8l.h:23-26,589-590).  The
+      // text is what the reference's tool prints for such a file (TooBigARGBImage prints from its constructor and main adds
+      // an empty line, exception.h:144-149, webp.cpp:186-188), so the command line tool's output stays the same.
+      if (w > 16384 || h > 16384) throw Error{"Too big ARGB Image. Max allowed width(height)=16384\n"};
     } else if (!memcmp(type, "PLTE", 4)) {
       plte.assign(data, data + len);
     } else if (!memcmp(type, "tRNS", 4)) {
@@ -132,12 +137,24 @@ inline Image read_png_bytes(const std::vector<uint8_t> &file) {
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (inflateInit(&zs) != Z_OK) throw Error{"PNG: zlib"};
-    zs.next_in = idat.data();
-    zs.avail_in = (uInt)idat.size();
-    zs.next_out = raw.data();
-    zs.avail_out = (uInt)raw.size();
-    const int rc = inflate(&zs, Z_FINISH);
-    const size_t got = raw.size() - zs.avail_out;
+    // zlib counts in 32 bits: both sides are fed in pieces of at most 1 GiB
+    const size_t piece = (size_t)1 << 30;
+    size_t in_pos = 0, got = 0;
+    int rc = Z_OK;
+    while (rc == Z_OK) {
+      if (zs.avail_in == 0 && in_pos < idat.size()) {
+        const size_t n = std::min(piece, idat.size() - in_pos);
+        zs.next_in = idat.data() + in_pos;
+        zs.avail_in = (uInt)n;
+        in_pos += n;
+      }
+      const size_t room = std::min(piece, raw.size() - got);
+      zs.next_out = raw.data() + got;
+      zs.avail_out = (uInt)room;
+      rc = inflate(&zs, in_pos == idat.size() ? Z_FINISH : Z_NO_FLUSH);
+      got += room - zs.avail_out;
+      if (rc == Z_BUF_ERROR || (got == raw.size() && rc == Z_OK)) break;  // no progress possible, or the image is complete
+    }
     inflateEnd(&zs);
     if ((rc != Z_STREAM_END && rc != Z_OK && rc != Z_BUF_ERROR) || got != raw.size()) throw Error{"PNG: bad image data"};
   }

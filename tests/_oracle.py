@@ -97,6 +97,11 @@ def lib():
 _ref = None
 
 
+def ref_available():
+    """Whether oracle/_ref was built (decided from the file's presence alone: nothing is loaded)."""
+    return os.path.exists(_REF_SO)
+
+
 def ref():
     """The compiled reference components, or None when oracle/_ref was not built (GPU box)."""
     global _ref

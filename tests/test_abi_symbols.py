@@ -46,3 +46,16 @@ def test_no_cpu_fallback_without_device():
         assert False, "encode must not succeed without a GPU"
     except webp_amd.Vp8lError as e:
         assert e.name == "NoDevice"
+
+
+def test_binding_refuses_short_pixel_arrays():
+    # the C ABI only gets a pointer: the binding must not let a short array through (it would be read past its end)
+    import numpy as np
+    import pytest
+    short = np.zeros(10, dtype=np.uint32)
+    with pytest.raises(webp_amd.Vp8lError) as ei:
+        webp_amd.encode(short, 4, 4)
+    assert ei.value.name == "InvalidARGBImage"
+    with pytest.raises(webp_amd.Vp8lError) as ei:
+        webp_amd.encode_batch([(np.zeros(16, dtype=np.uint32), 4, 4), (short, 4, 4)])
+    assert ei.value.name == "InvalidARGBImage"

@@ -132,3 +132,22 @@ def test_encode_then_decode_on_device():
     st = dec.decode_device([d_out.data_ptr() + int(off[0])], [int(lens[0])], [w], [h], [d_img.data_ptr()])
     assert st[0] == 0
     assert torch.equal(d_img, d_in)
+
+
+def test_hostile_group_count_inside_a_batch_of_valid_streams():
+    """A 40-byte stream whose meta-Huffman image asks for 65536 Huffman groups (or a few hundred) must get its own verdict
+    (the oracle's: the groups lie past the end of the stream) without costing the valid streams of the call theirs, and
+    without sizing any workspace by the count.  Streams that really hold many groups still decode."""
+    from test_host_cores import hostile_group_count_stream
+    imgs = [O.gen_image(m, 40, 30, 5 + m, 200) for m in (3, 4, 5)]
+    good = [O.encode(img, 40, 30)[1] for img in imgs]
+    many = O.gen_image(3, 64, 64, 9, 200)
+    rc, many_s = O.encode_ext(many, 64, 64, meta_bits=2, meta_groups=40, cache_bits=1)
+    assert rc == 0
+    bad = [hostile_group_count_stream(ix) for ix in (0xFFFF, 300, 5)]
+    streams = [good[0], bad[0], good[1], many_s, bad[1], good[2], bad[2]]
+    res = gpu_decode_all(streams)
+    for k, ref in ((0, imgs[0]), (2, imgs[1]), (5, imgs[2]), (3, many)):
+        assert res[k][0] == 0 and np.array_equal(res[k][1], ref)
+    for k in (1, 4, 6):
+        assert res[k][0] == O.decode(streams[k])[0] == -6

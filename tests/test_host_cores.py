@@ -217,3 +217,37 @@ def test_decoder_core_error_parity_on_corrupt_streams(K):
                 assert np.array_equal(out, ref)
                 agree += 1
     assert agree > 20
+
+
+def hostile_group_count_stream(index=0xFFFF, w=4, h=4):
+    """A few dozen bytes whose 1x1 meta-Huffman image holds `index`: the stream asks for index+1 Huffman groups
+    (vp8l.h:205-214) and ends before the first of them."""
+    bits = []
+
+    def put(v, n):
+        for i in range(n):
+            bits.append((v >> i) & 1)
+
+    def single(sym):  # simple code, one 8-bit symbol (huffman_io.h:152-178)
+        put(1, 1); put(0, 1); put(1, 1); put(sym, 8)
+
+    put(0, 32); put(0x2F, 8); put(w - 1, 14); put(h - 1, 14); put(0, 1); put(0, 3)
+    put(0, 1)        # no transform
+    put(0, 1)        # no colour cache
+    put(1, 1)        # meta-Huffman image follows
+    put(0, 3)        # its tiles are 4 pixels a side: one tile
+    put(0, 1)        # the entropy image has no colour cache
+    single(index & 0xFF)         # green
+    single((index >> 8) & 0xFF)  # red: index = red << 8 | green
+    single(0); single(0); single(0)
+    b = bits + [0] * ((-len(bits)) % 8)
+    return bytes(sum(b[i + k] << k for k in range(8)) for i in range(0, len(b), 8))
+
+
+@pytest.mark.parametrize("index", [0xFFFF, 300, 5, 1])
+def test_decoder_core_refuses_group_counts_the_stream_cannot_hold(K, index):
+    s = hostile_group_count_stream(index)
+    rc0, _, _, _ = O.decode(s)
+    rc, _, _, _ = core_decode(K, s, 4, 4)
+    assert rc0 == -6      # the groups lie past the end of the stream: zeros are no code (InvalidHuffman)
+    assert rc == rc0

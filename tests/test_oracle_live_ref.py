@@ -8,7 +8,7 @@ import pytest
 
 import _oracle as O
 
-pytestmark = pytest.mark.skipif(O.ref() is None, reason="oracle/_ref not built (no reference checkout here)")
+pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (no reference checkout here)")
 
 
 def test_lz77_random():

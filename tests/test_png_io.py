@@ -208,3 +208,19 @@ def test_broken_files_are_refused(tmp_path):
         open(path, "wb").write(bad)
         got, err = dump(path, tmp_path)
         assert got is None
+
+
+def test_header_sizes_beyond_the_codec_limit_allocate_nothing(tmp_path):
+    """A 60-byte file whose header claims 2^31 x 2^31 pixels is refused right after IHDR (the encoder's limit is 16384 a
+    side), quickly and with an error exit rather than an out-of-memory kill."""
+    import time
+    good = make_png(np.zeros((4, 4, 3), dtype=np.int64), 2, 8)
+    i = good.index(b"IHDR")
+    for w, h in ((1 << 31, 1 << 31), (16385, 4), (4, 16385)):
+        hdr = struct.pack(">II", w, h) + good[i + 12:i + 17]
+        bad = good[:i - 4] + _chunk(b"IHDR", hdr) + good[i + 21:]
+        path = str(tmp_path / "huge.png")
+        open(path, "wb").write(bad)
+        t0 = time.time()
+        got, err = dump(path, tmp_path)
+        assert got is None and time.time() - t0 < 5

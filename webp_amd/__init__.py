@@ -129,6 +129,9 @@ def encode(argb, width, height, predictor_bits=0, cross_color_bits=0):
     """VP8_LOSSLESS_ENCODER(argb, width, height).get_bit_writer() -> stream bytes (vp8l.h:585-615).
     predictor_bits 2..9 adds the predictor transform (not the reference encoder's bytes any more)."""
     a = None if argb is None else np.ascontiguousarray(argb, dtype=np.uint32)
+    # the C ABI cannot know the buffer's size (the C++ mirror checks the same, webp.hpp): a short array would be read past its end
+    if a is not None and a.size and max(int(width), int(height)) <= 16384 and a.size < int(width) * int(height):
+        raise Vp8lError(-1, "vp8l_encode (array holds %d pixels, %d x %d needs %d)" % (a.size, width, height, int(width) * int(height)))
     out = C.c_void_p()
     n = C.c_size_t()
     rc = lib().vp8l_encode(a.ctypes.data if a is not None and a.size else None, width, height, C.byref(out), C.byref(n), int(predictor_bits) | (int(cross_color_bits) << 4))
@@ -163,6 +166,9 @@ def encode_batch(images, device=-1):
     """images: list of (argb, w, h).  Returns list of (status, bytes)."""
     n = len(images)
     arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a, _, _ in images]
+    for a, (_, w, h) in zip(arrs, images):
+        if a.size and max(int(w), int(h)) <= 16384 and a.size < int(w) * int(h):  # larger sides get TooBigARGBImage from the library
+            raise Vp8lError(-1, "vp8l_encode_batch (an array holds %d pixels, %d x %d needs %d)" % (a.size, w, h, int(w) * int(h)))
     ptrs = (C.c_void_p * n)(*[a.ctypes.data if a.size else None for a in arrs])
     ws = (C.c_uint32 * n)(*[w for _, w, _ in images])
     hs = (C.c_uint32 * n)(*[h for _, _, h in images])

@@ -360,7 +360,7 @@ int encode_batch_with(int device, int pred_bits, size_t n, const uint32_t *const
 
 extern "C" int vp8l_encode_batch(int device, size_t n, const uint32_t *const *argb, const uint32_t *width,
                                  const uint32_t *height, uint8_t **out, size_t *out_len, int *status) {
-  return encode_batch_with(device, 0, n, argb, width, height, out, out_len, status);
+  return guarded([&] { return encode_batch_with(device, 0, n, argb, width, height, out, out_len, status); });
 }
 
 extern "C" int vp8l_encode(const uint32_t *argb, uint32_t width, uint32_t height, uint8_t **out, size_t *out_len, uint32_t flags) {
@@ -372,12 +372,13 @@ extern "C" int vp8l_encode(const uint32_t *argb, uint32_t width, uint32_t height
   if (!argb || width == 0 || height == 0) return VP8L_ERR_INVALID_ARGB;
   if (width > kMaxDim || height > kMaxDim) return VP8L_ERR_TOO_BIG_ARGB;
   int status = VP8L_OK;
-  const int rc = encode_batch_with(-1, pred_bits | (cross_bits << 4), 1, &argb, &width, &height, out, out_len, &status);
+  const int rc = guarded([&] { return encode_batch_with(-1, pred_bits | (cross_bits << 4), 1, &argb, &width, &height, out, out_len, &status); });
   return rc != VP8L_OK ? rc : status;
 }
 
-extern "C" int vp8l_decode_batch(int device, size_t n, const uint8_t *const *data, const size_t *len, uint32_t **argb,
-                                 uint32_t *width, uint32_t *height, int *status) {
+namespace {
+int decode_batch_impl(int device, size_t n, const uint8_t *const *data, const size_t *len, uint32_t **argb,
+                      uint32_t *width, uint32_t *height, int *status) {
   if (!data || !len || !argb || !width || !height || !status) return VP8L_ERR_BAD_ARGUMENT;
   if (n == 0) return VP8L_OK;
   Pipeline *p = nullptr;
@@ -443,6 +444,13 @@ extern "C" int vp8l_decode_batch(int device, size_t n, const uint8_t *const *dat
     for (size_t i = 0; i < n; i++) { vp8l_free(argb[i]); argb[i] = nullptr; }
   }
   return rc;
+}
+
+}  // namespace
+
+extern "C" int vp8l_decode_batch(int device, size_t n, const uint8_t *const *data, const size_t *len, uint32_t **argb,
+                                 uint32_t *width, uint32_t *height, int *status) {
+  return guarded([&] { return decode_batch_impl(device, n, data, len, argb, width, height, status); });
 }
 
 extern "C" int vp8l_decode(const uint8_t *data, size_t len, uint32_t **argb, uint32_t *width, uint32_t *height) {

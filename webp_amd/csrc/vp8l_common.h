@@ -6,7 +6,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define VP8L_HD __host__ __device__ __forceinline__
 #else
 #define VP8L_HD inline

@@ -550,6 +550,12 @@ VP8L_HD uint32_t dec_step(DecState &st, const DecAccel &acc = DecAccel()) {
       }
       case kPhGroups: {  // vp8l.h:217-222
         if (st.ngroups > 1) {
+          // A group takes at least 20 stream bits (five one-symbol codes of 4 bits, huffman_io.h:152-178) and one that starts
+          // past the stream's end reads zeros only, which is no code (InvalidHuffman).  So a count the rest of the stream
+          // cannot hold is refused before any workspace is sized by it (a 0xffff index in a tiny stream asks for 65536 groups).
+          const uint64_t pos_bits = br.bytepos * 8 - br.cnt, len_bits = br.len * 8;
+          const uint64_t bits_left = len_bits > pos_bits ? len_bits - pos_bits : 0;
+          if ((uint64_t)(st.ngroups - 1) * 20 > bits_left) VP8L_FAIL(kErrInvalidHuffman);
           if (st.ngroups > st.multi_cap) { st.need_groups = st.ngroups; VP8L_FAIL(kErrWorkspace); }
           st.groups = st.groups_multi;
         }

@@ -2110,7 +2110,7 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
 
 }  // namespace
 
-extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8_t *const *d_data, const size_t *len,
+static int vp8l_decoder_decode_device_impl(vp8l_decoder *d, size_t n, const uint8_t *const *d_data, const size_t *len,
                                           const uint32_t *width, const uint32_t *height, uint32_t *const *d_argb, int *status) {
   if (!d || !d_data || !len || !width || !height || !d_argb || !status) return VP8L_ERR_BAD_ARGUMENT;
   if (n == 0) return VP8L_OK;
@@ -2161,26 +2161,33 @@ extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8
     todo.pop_back();
     std::vector<DecResult> results;
     const int rc = decode_pass(d, t.idx, d_data, len, width, height, d_argb, t.group_cap, t.mode, t.pred_bands, results);
-    if (rc == VP8L_ERR_NO_MEMORY && t.mode != 0) {
-      // no room for the segment kernels' workspace: half the streams at a time, a single stream by one workgroup
+    if (t.group_cap > 64) {  // a stream with thousands of groups sized these tables: not kept for the calls that follow
+      d->d_groups.release();
+      d->d_sorted.release();
+    }
+    if (rc == VP8L_ERR_NO_MEMORY) {
+      // no room for this pass's workspace: half the streams at a time; a single stream first without the segment kernels'
+      // workspace (one workgroup), and if even that does not fit, the stream alone gets the verdict, not the call
       (void)hipGetLastError();  // the failed allocation is dealt with here; the next pass checks for launch errors
       if (t.idx.size() > 1) {
         const size_t half = t.idx.size() / 2;
         todo.push_back({std::vector<uint32_t>(t.idx.begin() + half, t.idx.end()), t.mode, t.group_cap, t.pred_bands});
         todo.push_back({std::vector<uint32_t>(t.idx.begin(), t.idx.begin() + half), t.mode, t.group_cap, t.pred_bands});
-      } else {
+      } else if (t.mode != 0) {
         todo.push_back({t.idx, 0, t.group_cap, t.pred_bands});
+      } else {
+        status[t.idx[0]] = VP8L_ERR_NO_MEMORY;
       }
       continue;
     }
     if (rc != VP8L_OK) return rc;
-    Todo more_groups{{}, t.mode, t.group_cap, t.pred_bands}, with_maps{{}, 2, t.group_cap, t.pred_bands}, one_workgroup{{}, 0, t.group_cap, t.pred_bands},
+    Todo with_maps{{}, 2, t.group_cap, t.pred_bands}, one_workgroup{{}, 0, t.group_cap, t.pred_bands},
         one_block_predictor{{}, t.mode, t.group_cap, false};
     for (size_t k = 0; k < t.idx.size(); k++) {
       const DecResult &r = results[k];
       if (r.status == kErrWorkspace && r.need_groups > t.group_cap) {
-        more_groups.idx.push_back(t.idx[k]);
-        more_groups.group_cap = std::max(more_groups.group_cap, r.need_groups);
+        // a pass sizes every image's tables by one count: an image that needs more gets a pass of its own with exactly its count
+        todo.push_back({std::vector<uint32_t>(1, t.idx[k]), t.mode, r.need_groups, t.pred_bands});
       } else if (r.status == kPredRetry) {
         one_block_predictor.idx.push_back(t.idx[k]);  // a band of the predictor inverse waited too long for the band above
       } else if (r.status == kParRetryMaps && t.mode == 1) {
@@ -2193,10 +2200,15 @@ extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8
         if (t.mode == 1 && r.pad == 1) d->last_scouted++;
       }
     }
-    for (Todo *n2 : {&more_groups, &with_maps, &one_workgroup, &one_block_predictor})
+    for (Todo *n2 : {&with_maps, &one_workgroup, &one_block_predictor})
       if (!n2->idx.empty()) todo.push_back(std::move(*n2));
   }
   return VP8L_OK;
+}
+
+extern "C" int vp8l_decoder_decode_device(vp8l_decoder *d, size_t n, const uint8_t *const *d_data, const size_t *len,
+                                          const uint32_t *width, const uint32_t *height, uint32_t *const *d_argb, int *status) {
+  return (int)guarded([&] { return (int)vp8l_decoder_decode_device_impl(d, n, d_data, len, width, height, d_argb, status); });
 }
 
 extern "C" long vp8l_decoder_last_whole_device_streams(const vp8l_decoder *d) { return d ? (long)d->last_whole_device : 0; }

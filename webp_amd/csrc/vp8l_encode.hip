@@ -1641,7 +1641,7 @@ extern "C" void vp8l_encoder_destroy(vp8l_encoder *e) {
   delete e;
 }
 
-extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint32_t *const *d_argb, const uint32_t *width,
+static int vp8l_encoder_encode_device_impl(vp8l_encoder *e, size_t n, const uint32_t *const *d_argb, const uint32_t *width,
                                           const uint32_t *height, uint8_t *d_out, size_t out_cap, size_t *out_offset,
                                           size_t *out_len, int *status) {
   if (!e || !d_argb || !width || !height || !d_out || !out_offset || !out_len || !status) return VP8L_ERR_BAD_ARGUMENT;
@@ -1765,6 +1765,12 @@ extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint3
     e->states.swap(stidx);
   }
   return VP8L_OK;
+}
+
+extern "C" int vp8l_encoder_encode_device(vp8l_encoder *e, size_t n, const uint32_t *const *d_argb, const uint32_t *width,
+                                          const uint32_t *height, uint8_t *d_out, size_t out_cap, size_t *out_offset,
+                                          size_t *out_len, int *status) {
+  return (int)guarded([&] { return (int)vp8l_encoder_encode_device_impl(e, n, d_argb, width, height, d_out, out_cap, out_offset, out_len, status); });
 }
 
 extern "C" long vp8l_encoder_fetch_stage(vp8l_encoder *e, size_t image, int what, void *host_buf, size_t cap) {

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <exception>
 #include <new>
 #include <string>
 
@@ -19,6 +20,22 @@ bool hip_ok(hipError_t e, const char *what);
 
 // device < 0 keeps the current device.  Fails with VP8L_ERR_NO_DEVICE when no gfx950 is usable.
 int select_device(int device, int *chosen);
+
+// No C++ exception may cross the C boundary: allocation failures of the host-side containers and threads become
+// VP8L_ERR_NO_MEMORY, anything else VP8L_ERR_HIP with its text in vp8l_last_error().
+template <class Body>
+int guarded(Body body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    return VP8L_ERR_NO_MEMORY;
+  } catch (const std::exception &e) {
+    try { last_error_slot() = std::string("host exception: ") + e.what(); } catch (...) {}
+    return VP8L_ERR_HIP;
+  } catch (...) {
+    return VP8L_ERR_HIP;
+  }
+}
 
 // Looks up the address of the static no-allocation workspace on every device (vp8l_encode.hip).
 void noalloc_setup_all_devices();
