@@ -301,3 +301,22 @@ def test_whole_device_when_scouts_cannot_fall_in_step(scout_form):
     (st, px), = decode_with(1024, [s3], whole_device=2, used=used, scout_form=scout_form)
     assert st == 0 and np.array_equal(px, img3)
     assert used == [1, 0], used
+
+
+def test_lane_scouts_built_with_512_threads():
+    """The lane scouts (k_par_scout_lanes) are written for any whole number of waves per workgroup; the shipped library
+    uses 256 threads, libvp8l_amd_lanes512.so is the same source built with 512.  Every case of this file must give the
+    same pixels, verdicts and scout counts with it (the cases run in a child process that loads that library)."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("VP8L_AMD_LIB"):
+        pytest.skip("already running on another build of the library")
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(os.path.dirname(here), "webp_amd", "csrc", "libvp8l_amd_lanes512.so")
+    assert os.path.exists(lib), "build the test variant first (__graft_entry__.build())"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "--timeout", "120", "--timeout-method", "thread"],
+                       env=dict(os.environ, VP8L_AMD_LIB=lib), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

@@ -84,3 +84,43 @@ def test_largest_dimensions_round_trip(w, h):            # configs[2]: 16383 is 
     d_out, off, lens, info = encode(torch, d_in, w, h)
     assert all(i["M"] == w * h for i in info)
     assert torch.equal(decode(torch, d_out, off, lens, w, h), d_in)
+
+
+def _big_cases():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big16k.json")
+    return json.load(open(path))
+
+
+@pytest.mark.parametrize("case", _big_cases(), ids=lambda c: "mode%d" % c["mode"])
+def test_single_16383x16383_image_against_the_oracles_known_answer(case):   # configs[2] as BASELINE names it
+    """One image of the largest VP8L size on one GPU.  Default path: the stream's size and sha256 equal what the CPU
+    oracle produced for the same pixels (tests/golden/make_big16k.py, run once in the build container: minutes of
+    brute-force match search), and the stream decodes back on the device.  With the predictor transform (tile-parallel
+    mode search + residuals in front of the same LZ77 coder): decodes back to the input."""
+    import hashlib
+    import torch
+    w, h = case["w"], case["h"]
+    d_in = gen(torch, [(case["mode"], case["seed"], 0)], w, h)
+    assert hashlib.sha256(d_in[0].cpu().numpy().tobytes()).hexdigest() == case["pixels_sha256"]   # same pixels as the oracle's generator
+    d_out, off, lens, info = encode(torch, d_in, w, h)
+    assert info[0]["M"] == w * h and info[0]["ncolors"] == 0
+    assert int(lens[0]) == case["bytes"]
+    (s,) = streams(d_out, off, lens)
+    assert hashlib.sha256(s).hexdigest() == case["sha256"]
+    del s
+    assert torch.equal(decode(torch, d_out, off, lens, w, h), d_in)
+    del d_out
+    # predictor + LZ77 (not the reference encoder's bytes: checked by decoding)
+    enc = webp_amd.Encoder()
+    enc.set_predictor_bits(5)
+    cap = enc.bound(w, h)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    off, lens, st = enc.encode_device([d_in[0].data_ptr()], [w], [h], d_out.data_ptr(), cap)
+    assert st[0] == 0
+    modes = enc.fetch_stage(0, webp_amd.STAGE_PRED_MODES)
+    enc.close()
+    assert modes is not None and modes["tx"] * modes["ty"] <= 1024 and (modes["tx"] << modes["bits"]) >= w
+    assert int(lens[0]) < case["bytes"]          # the predictor pays on both generators
+    assert torch.equal(decode(torch, d_out, off, lens, w, h), d_in)

@@ -19,7 +19,8 @@ import numpy as np
 import torch  # noqa: F401  (device memory, streams and torch.distributed come from it anyway)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvp8l_amd.so")
+# VP8L_AMD_LIB: another build of the same library (kernel experiments); there is still no fallback of any kind
+LIB_PATH = os.environ.get("VP8L_AMD_LIB") or os.path.join(_HERE, "csrc", "libvp8l_amd.so")
 
 OK = 0
 STATUS_NAMES = {

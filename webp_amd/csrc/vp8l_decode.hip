@@ -1156,7 +1156,10 @@ __global__ __launch_bounds__(kWgThreads, 8) void k_par_scout(const DecImage *__r
 // k_par_verify and k_par_place follow.
 constexpr uint32_t kLaneBits = 8192;
 constexpr uint32_t kLanesPerSeg = kParSegBits / kLaneBits;
-constexpr uint32_t kLaneThreads = 256;
+#ifndef VP8L_LANE_THREADS
+#define VP8L_LANE_THREADS 256
+#endif
+constexpr uint32_t kLaneThreads = VP8L_LANE_THREADS;  // 256 or 512 (a compile-time choice, kept for experiments)
 constexpr uint32_t kLaneSegsPerWg = kLaneThreads / kLanesPerSeg - 1;  // the last lane of the first group has the warm-up piece
 constexpr uint32_t kLaneChunkWords = 4;                               // 64-bit words of every piece loaded at a time
 constexpr uint32_t kLaneChunkBits = 64 * kLaneChunkWords;
@@ -1170,6 +1173,10 @@ static_assert(4 + kLanesPerSeg <= 64, "a segment's slots hold the lanes' record 
 static_assert(kLaneBits < kParSegBits && (kLanesPerSeg & (kLanesPerSeg - 1)) == 0 && kLanesPerSeg <= 64, "the lanes of a segment sit in one wave");
 static_assert(kLaneThreads % 64 == 0 && kLaneThreads >= kNumCodes * kWgLongSlots, "whole waves; one thread per long-code slot");
 static_assert(64 % kLaneChunkWords == 0 && kLaneBits % kLaneChunkBits == 0 && kLaneBits % 64 == 0, "chunks");
+// What the kernel assumes about its workgroup size, so that it can be built with 256 or 512 threads (both are tested):
+static_assert(kParStop < 256 && kParStop > 63 && kParNone < 256, "exit codes and the bit offsets 0..63 fit the uint8_t exit_off entries");
+static_assert(kLaneThreads / kLanesPerSeg >= 2, "a workgroup holds the warm-up piece's group of lanes and at least one segment");
+static_assert(kLaneThreads <= 1024, "one workgroup");
 
 struct LaneShared {
   uint32_t lim[kNumCodes][kWgLongSlots];   // as in WgShared
@@ -1262,6 +1269,7 @@ __device__ __forceinline__ void lanes_pass(const LaneStream &ls, uint32_t s0, bo
   if (run) { out = stopped ? kParStop : rel - kLaneBits; ntok = tok; npx = px; }
 }
 
+static_assert(sizeof(LaneShared) + sizeof(GroupTables) <= (64u << 10), "static LDS of k_par_scout_lanes");
 __global__ __launch_bounds__(kLaneThreads, 5) void k_par_scout_lanes(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ wgfirst, uint32_t n) {
   __shared__ GroupTables g_;
   __shared__ __attribute__((aligned(16))) LaneShared sh_;
