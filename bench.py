@@ -7,16 +7,24 @@ A "step" is one pass of the whole encode path over that batch with the inputs al
 HBM; the streams stay in HBM.  With N GPUs every rank encodes its own batch of the same size (images
 are independent: no collective on the data path), so value = pixels of all ranks / slowest rank.
 
+`python bench.py --gpus N` without a launcher's environment starts N ranks itself (one child process per
+GPU, before this process touches a GPU); under torch.distributed.run it is one of the ranks.
+
 Prints ONE JSON line on rank 0.  Extra objects in that line:
-  roofline      the dominant kernel (k_lz77_sparse, the match search, which also makes the subtract-green
-                residual): algorithmic bytes (13 B per coded pixel: 4 read; residual 4, match 4 and
-                advance 1 written) over its mean launch duration, measured here with HIP
-                events on the encoder's stream; "traffic" is the HBM byte count of one launch from the
-                committed rocprofv3 counter passes (profiles/lz77_traffic.json), null if none fits
-  cpu_baseline  the CPU oracle (a port of the reference's single-threaded algorithm, image-parallel
-                over host threads) on a bounded sample of the same images, rank 0 at N=1 only
+  roofline         the dominant kernel (the match search, which also makes the subtract-green residual): algorithmic
+                   bytes over its mean launch duration, measured here with HIP events on the encoder's stream;
+                   "traffic" is the HBM byte count of one launch from the committed rocprofv3 counter passes
+                   (profiles/lz77_traffic.json), null if none fits this batch
+  roofline_stages  every stage of the encode path: algorithmic bytes per coded pixel, ms per step, fraction of HBM peak;
+                   and the sum of the stages' bytes against the fused ideal (4 + bpp/8 bytes per pixel)
+  decode           the same streams decoded back on the device: MP/s over >= 3 timed repetitions and its roofline
+  host_to_host     pinned host memory -> pinned host memory through vp8l_encode_batch / vp8l_decode_batch (PCIe included;
+                   never `value`)
+  cpu_baseline     the CPU oracle (a port of the reference's single-threaded algorithm, image-parallel
+                   over host threads) on a bounded sample of the same images, rank 0 at N=1 only
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -33,7 +41,31 @@ import webp_amd  # noqa: E402
 from webp_amd import sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
-LZ77_BYTES_PER_PIXEL = 13.0    # 4 B pixel read; 4 B residual + 4 B (length, distance, code) + 1 B advance written
+
+
+def stage_bytes_per_pixel(bpp):
+    """Algorithmic HBM bytes per coded pixel of every encode stage (reads + writes each stage cannot avoid given the
+    arrays it is handed), keyed like Encoder.last_stage_seconds()."""
+    return {
+        "palette": 4.0,                      # every pixel read once (photo-like images stop after a few hundred pixels per block)
+        "transform": 8.0,                    # only images the match kernel does not transform itself
+        "match": 13.0,                       # 4 read; residual 4 + match 4 + advance 1 written
+        "parse": 2.0 + 1.0 / 8 + 1.0 / 128,  # advances read twice, token-start bits written, block exits
+        "histogram": 8.0 + 1.0 / 8,          # residual + match + token-start bits read
+        "header": 0.0,                       # per image, not per pixel
+        "bitcount_scan": 8.0 + 2.0 / 8,      # residual + match + bits read, bit counts per 16 positions written
+        "emit": 8.0 + 2.0 / 8 + bpp / 8.0,   # the same read again, the stream written
+    }
+
+
+def host_threads():
+    """Host threads for the CPU baseline: the cores this process may run on, capped by the share the box gives one GPU's
+    job (OMP_NUM_THREADS there; os.cpu_count() shows the whole machine's CPUs, many times as many)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share = os.environ.get("OMP_NUM_THREADS")
+    if share and share.isdigit() and int(share) > 0:
+        n = min(n, int(share))
+    return max(1, n)
 
 
 def cpu_baseline(w, h, plan, threads, budget_images):
@@ -61,13 +93,11 @@ def cpu_baseline(w, h, plan, threads, budget_images):
         "sample": "%d of the benchmark's %dx%d images (modes %s), one image per host thread, %.1f s wall"
                   % (len(imgs), w, h, "".join(str(m) for m, _ in sample), dt),
         "single_thread_value": one,
+        "host_cpus_visible": os.cpu_count(),
         "bytes": int(sum(sizes)),
     }
 
 
-# ---------------------------------------------------------------------------------------------
-# The other BASELINE configurations (not the headline line; same JSON shape, one line each).
-# ---------------------------------------------------------------------------------------------
 def _fence(world):
     torch.cuda.synchronize()
     if world > 1:
@@ -103,6 +133,28 @@ def _base_line(args, world, metric, value, elapsed, workload, extra):
     return out
 
 
+def _timed_decode(dec, dargs, npx_total, reps):
+    """Device-resident decode of a batch: one untimed call (workspace), then `reps` timed ones.  Returns (MP/s over the
+    wall clock of the timed calls, mean device seconds per call, status of the last call)."""
+    st = dec.decode_device(*dargs)
+    torch.cuda.synchronize()
+    dev_s = []
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        st = dec.decode_device(*dargs)
+        dev_s.append(dec.last_device_seconds())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return reps * npx_total / 1e6 / dt, float(np.mean(dev_s)), st
+
+
+def _decode_roofline(bpp, npx_total, dev_s):
+    alg = (bpp / 8.0 + 4.0) * npx_total   # stream bytes read + pixels written
+    return {"kernel": "whole decode path (k_par_scout_lanes, k_par_place, k_par_jump, inverse transforms) over the end-to-end algorithmic bytes",
+            "bound": "hbm", "achieved": alg / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dev_s / 1e9 / HBM_PEAK_GBS,
+            "traffic": None, "algorithmic_bytes_per_launch": alg}
+
+
 def workload_decode1080p(args, world, rank, local_rank, dev):
     """BASELINE configs[3]: 4096 1920x1080 streams over 8 GPUs = 512 per GPU, half photo-like, half graphics."""
     w, h, batch = 1920, 1080, 512
@@ -133,19 +185,16 @@ def workload_decode1080p(args, world, rank, local_rank, dev):
         return None
     bpp = 8.0 * float(lens.sum()) / (batch * npx)
     dev_s = float(np.mean(dev_times[args.warmup:]))
-    alg = (bpp / 8.0 + 4.0) * batch * npx  # stream bytes read + pixels written
     out = _base_line(args, world, "vp8l_decode_megapixels_per_sec", total_px / 1e6 / elapsed, elapsed,
                      "batch of %d synthetic %dx%d streams per rank (half photo-like, half graphics), VP8L decode "
                      "(BASELINE configs[3] = 4096 streams over 8 GPUs); streams and pixels resident in HBM" % (batch, w, h),
                      {"bits_per_pixel": bpp, "roundtrip_verified": ok, "device_ms_per_step": 1e3 * dev_s,
-                      "roofline": {"kernel": "whole decode path (k_par_scout_lanes, k_par_place, k_par_jump, inverse transforms) over the end-to-end algorithmic bytes", "bound": "hbm",
-                                   "achieved": alg / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dev_s / 1e9 / HBM_PEAK_GBS,
-                                   "traffic": None, "algorithmic_bytes_per_launch": alg}})
+                      "roofline": _decode_roofline(bpp, batch * npx, dev_s)})
     out["cpu_baseline"] = None
     if world == 1 and not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import _oracle as O
-        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+        threads = args.cpu_threads or host_threads()
         sample = [bytes(d_out[int(off[k]):int(off[k]) + int(lens[k])].cpu().numpy()) for k in range(threads)]
         t0 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=threads) as ex:
@@ -153,11 +202,27 @@ def workload_decode1080p(args, world, rank, local_rank, dev):
         dt = time.perf_counter() - t0
         assert all(r == 0 for r in rcs)
         out["cpu_baseline"] = {"value": len(sample) * npx / 1e6 / dt, "unit": "MP/s", "cores": threads, "kind": "port",
+                               "host_cpus_visible": os.cpu_count(),
                                "sample": "%d of the benchmark's streams, one per host thread, %.1f s wall" % (len(sample), dt)}
     return out
 
 
-def _encode_workload(args, world, rank, local_rank, dev, w, h, plan, workload, metric="vp8l_encode_megapixels_per_sec"):
+def _stage_table(stage_ms, bpp, npx_total):
+    per_px = stage_bytes_per_pixel(bpp)
+    rows, total_bytes = [], 0.0
+    for name, ms in stage_ms.items():
+        if name not in per_px:
+            continue
+        b = per_px[name]
+        total_bytes += b
+        gbs = b * npx_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        rows.append({"stage": name, "alg_bytes_per_px": round(b, 4), "ms": ms, "GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
+    ideal = 4.0 + bpp / 8.0
+    return rows, {"sum_of_stages": total_bytes, "fused_ideal": ideal, "ratio": total_bytes / ideal}
+
+
+def _encode_workload(args, world, rank, local_rank, dev, w, h, plan, workload, metric="vp8l_encode_megapixels_per_sec",
+                     predictor_bits=0, with_predictor_variant=False):
     batch = len(plan)
     npx = w * h
     webp_amd.init()
@@ -165,6 +230,8 @@ def _encode_workload(args, world, rank, local_rank, dev, w, h, plan, workload, m
     for k, (mode, seed, ncol) in enumerate(plan):
         webp_amd.generate_device(mode, w, h, seed, ncol, d_in[k].data_ptr(), device=local_rank)
     enc = webp_amd.Encoder(local_rank)
+    if predictor_bits:
+        enc.set_predictor_bits(predictor_bits)
     ws, hs = [w] * batch, [h] * batch
     d_out, ptrs = _encode_batch_on_device(enc, d_in, ws, hs, dev)
     res = {}
@@ -179,27 +246,43 @@ def _encode_workload(args, world, rank, local_rank, dev, w, h, plan, workload, m
 
     total_px, elapsed = _timed_steps(args, world, dev, step, batch * npx)
     off, lens, status = res["r"]
-    ok, dec_ms = None, None
+    dense, tiles = enc.last_dense_tiles()
+    ok, decode = None, None
+    bpp = 8.0 * float(lens.sum()) / (batch * npx)
     if not args.no_verify:
         dec = webp_amd.Decoder(local_rank)
         d_dec = torch.empty((batch, npx), dtype=torch.int32, device=dev)
         dargs = ([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], ws, hs, [d_dec[k].data_ptr() for k in range(batch)])
-        dec.decode_device(*dargs)
-        st = dec.decode_device(*dargs)
-        dec_ms = 1e3 * dec.last_device_seconds()
+        mps, dsec, st = _timed_decode(dec, dargs, batch * npx, 3)
         ok = bool((st == 0).all() and torch.equal(d_dec, d_in))
+        decode = {"value": mps, "unit": "MP/s", "reps": 3, "device_ms": 1e3 * dsec, "roofline": _decode_roofline(bpp, batch * npx, dsec)}
+        del d_dec, dec
+    extra_variant = None
+    if with_predictor_variant:
+        del d_out
+        enc.close()
+        torch.cuda.empty_cache()
+        sub = argparse.Namespace(**vars(args))
+        sub.no_cpu = True
+        extra_variant = _encode_workload(sub, world, rank, local_rank, dev, w, h, plan, workload + " -- with the predictor transform (tiles of 32)",
+                                         metric, predictor_bits=5)
     if rank != 0:
         return None
-    bpp = 8.0 * float(lens.sum()) / (batch * npx)
     dev_s = float(np.mean(dev_times[args.warmup:]))
     alg = (4.0 + bpp / 8.0) * batch * npx  # the fused ideal: every pixel read once, the stream written once
     n = len(dev_times)
+    stage_ms = {k2: 1e3 * v / n for k2, v in stage_acc.items()}
+    rows, sums = _stage_table(stage_ms, bpp, batch * npx)
     out = _base_line(args, world, metric, total_px / 1e6 / elapsed, elapsed, workload,
-                     {"bits_per_pixel": bpp, "roundtrip_verified": ok, "decode_device_ms": dec_ms, "device_ms_per_step": 1e3 * dev_s,
-                      "stage_ms_per_step": {k2: 1e3 * v / n for k2, v in stage_acc.items()},
+                     {"bits_per_pixel": bpp, "roundtrip_verified": ok, "decode": decode, "device_ms_per_step": 1e3 * dev_s,
+                      "stage_ms_per_step": stage_ms, "roofline_stages": rows, "encode_bytes_per_pixel": sums,
+                      "exhaustive_search_tiles": {"tiles": dense, "of": tiles},
                       "roofline": {"kernel": "whole encode path", "bound": "hbm", "achieved": alg / dev_s / 1e9, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": alg / dev_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                    "algorithmic_bytes_per_launch": alg}})
+    if extra_variant is not None:
+        out["predictor_variant"] = {k2: extra_variant[k2] for k2 in ("value", "ms_per_step", "bits_per_pixel", "roundtrip_verified", "decode",
+                                                                       "device_ms_per_step", "stage_ms_per_step", "exhaustive_search_tiles")}
     out["cpu_baseline"] = None
     if world == 1 and not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -226,48 +309,76 @@ def workload_palette2k(args, world, rank, local_rank, dev):
 
 
 def workload_single16k(args, world, rank, local_rank, dev):
-    """BASELINE configs[2]: one 16383x16383 image on one GPU (every rank encodes its own: replicas)."""
+    """BASELINE configs[2]: one 16383x16383 image on one GPU (every rank encodes its own: replicas), without and with the
+    tile-parallel predictor in front of the LZ77 coder."""
     plan = [(4, 4242 + rank, 0)]
     return _encode_workload(args, world, rank, local_rank, dev, 16383, 16383, plan,
                             "one synthetic 16383x16383 graphics image per rank (maximum VP8L size), VP8L encode (BASELINE configs[2]); "
-                            "input and stream resident in HBM")
+                            "input and stream resident in HBM", with_predictor_variant=True)
 
 
-OTHER_WORKLOADS = {"decode1080p": workload_decode1080p, "palette2k": workload_palette2k, "single16k": workload_single16k}
+def workload_predictor4k(args, world, rank, local_rank, dev):
+    """The headline batch's content with the predictor transform switched on (not the reference encoder's bytes)."""
+    plan = [(m, s, 0) for m, s in sharding.bench_image_plan(64, rank)]
+    return _encode_workload(args, world, rank, local_rank, dev, 3840, 2160, plan,
+                            "batch of 64 synthetic 3840x2160 images per rank, predictor transform (tiles of 32) + VP8L encode; inputs and "
+                            "streams resident in HBM", predictor_bits=5)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = min(16, cores))")
-    ap.add_argument("--cpu-images", type=int, default=0, help="images in the CPU-baseline sample (0 = one per thread)")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--workload", default="encode4k", choices=sorted(OTHER_WORKLOADS) + ["encode4k"],
-                    help="encode4k = BASELINE configs[1] (the headline line); the others measure configs[2..4]")
-    args = ap.parse_args()
+OTHER_WORKLOADS = {"decode1080p": workload_decode1080p, "palette2k": workload_palette2k, "single16k": workload_single16k,
+                   "predictor4k": workload_predictor4k}
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    if args.workload != "encode4k":
-        out = OTHER_WORKLOADS[args.workload](args, world, rank, local_rank, dev)
-        if rank == 0:
-            print(json.dumps(out))
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
 
+def host_to_host(local_rank, d_in, w, h, images):
+    """vp8l_encode_batch / vp8l_decode_batch from page-locked host memory to page-locked host memory (the library returns
+    its results in page-locked blocks), wall clock around the calls: what a caller with host buffers sees."""
+    L = webp_amd.lib()
+    n = min(images, d_in.shape[0])
+    npx = w * h
+    host = torch.empty((n, npx), dtype=torch.int32, pin_memory=True)
+    host.copy_(d_in[:n])
+    torch.cuda.synchronize()
+    ptrs = (C.c_void_p * n)(*[host[k].data_ptr() for k in range(n)])
+    ws = (C.c_uint32 * n)(*([w] * n))
+    hs = (C.c_uint32 * n)(*([h] * n))
+    status = (C.c_int * n)()
+    enc_s, dec_s = [], []
+    outs = lens = None
+    for rep in range(3):   # the first call builds the lanes' contexts and staging buffers
+        if outs is not None:
+            for k in range(n):
+                L.vp8l_free(C.c_void_p(outs[k]))
+        outs = (C.c_void_p * n)()
+        lens = (C.c_size_t * n)()
+        t0 = time.perf_counter()
+        rc = L.vp8l_encode_batch(local_rank, n, ptrs, ws, hs, outs, lens, status)
+        enc_s.append(time.perf_counter() - t0)
+        assert rc == 0 and all(s == 0 for s in status), (rc, list(status))
+    ok = True
+    for rep in range(3):
+        argb = (C.c_void_p * n)()
+        ow = (C.c_uint32 * n)()
+        oh = (C.c_uint32 * n)()
+        t0 = time.perf_counter()
+        rc = L.vp8l_decode_batch(local_rank, n, outs, lens, argb, ow, oh, status)
+        dec_s.append(time.perf_counter() - t0)
+        assert rc == 0 and all(s == 0 for s in status), (rc, list(status))
+        if rep == 2:
+            for k in range(0, n, max(1, n // 8)):
+                got = np.ctypeslib.as_array(C.cast(argb[k], C.POINTER(C.c_uint32)), shape=(npx,))
+                ok = ok and bool(np.array_equal(got, host[k].numpy().view(np.uint32)))
+        for k in range(n):
+            L.vp8l_free(C.c_void_p(argb[k]))
+    for k in range(n):
+        L.vp8l_free(C.c_void_p(outs[k]))
+    e, d = min(enc_s[1:]), min(dec_s[1:])
+    return {"encode": n * npx / 1e6 / e, "decode": n * npx / 1e6 / d, "unit": "MP/s", "images": n,
+            "encode_GBps_in": n * npx * 4 / 1e9 / e, "decode_GBps_out": n * npx * 4 / 1e9 / d, "roundtrip_verified": ok,
+            "what": "page-locked host memory in, page-locked host memory out, through vp8l_encode_batch / vp8l_decode_batch; best of 2 "
+                    "calls after one that builds the staging buffers; PCIe both ways included"}
+
+
+def workload_encode4k(args, world, rank, local_rank, dev):
     w, h, batch = args.width, args.height, args.batch
     npx = w * h
     plan = sharding.bench_image_plan(batch, rank)
@@ -286,17 +397,11 @@ def main():
     def step():
         return enc.encode_device(in_ptrs, ws, hs, d_out.data_ptr(), d_out.numel())
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         off, lens, status = step()
         assert (status == 0).all(), status
     lz_times, dev_times, stage_acc = [], [], {}
-    fence()
+    _fence(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         off, lens, status = step()
@@ -305,7 +410,7 @@ def main():
         dev_times.append(enc.last_device_seconds())
         for k2, v in st.items():
             stage_acc[k2] = stage_acc.get(k2, 0.0) + v
-    fence()
+    _fence(world)
     elapsed = time.perf_counter() - t0
     assert (status == 0).all(), status
     total_px, elapsed = sharding.global_throughput(batch * npx * args.steps, elapsed, dev)
@@ -313,62 +418,109 @@ def main():
     total_bytes = int(lens.sum())
     bpp = 8.0 * total_bytes / (batch * npx)
 
-    # ---- correctness of what was just measured (outside the timed region) ---------------------
-    verify = None
-    decode_mps = None
+    # ---- correctness of what was just measured (outside the timed region), and the decode figure -------------
+    verify, decode = None, None
     if not args.no_verify:
         dec = webp_amd.Decoder(local_rank)
         d_dec = torch.empty((batch, npx), dtype=torch.int32, device=dev)
         dargs = ([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], ws, hs,
                  [d_dec[k].data_ptr() for k in range(batch)])
-        stt = dec.decode_device(*dargs)          # first call allocates the workspace
+        mps, dsec, stt = _timed_decode(dec, dargs, batch * npx, 3)
         verify = bool((stt == 0).all() and torch.equal(d_dec, d_in))
-        d_dec.zero_()
-        torch.cuda.synchronize()
-        td = time.perf_counter()
-        stt = dec.decode_device(*dargs)
-        torch.cuda.synchronize()
-        td = time.perf_counter() - td
-        verify = verify and bool((stt == 0).all() and torch.equal(d_dec, d_in))
-        decode_mps = batch * npx / 1e6 / td
-        del d_dec
+        decode = {"value": mps, "unit": "MP/s", "reps": 3, "device_ms": 1e3 * dsec, "roofline": _decode_roofline(bpp, batch * npx, dsec)}
+        del d_dec, dec
+        torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = total_px / 1e6 / elapsed
+    lz_avg = float(np.mean(lz_times))
+    lz_bytes = stage_bytes_per_pixel(bpp)["match"]
+    achieved = lz_bytes * batch * npx / lz_avg / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "lz77_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("batch") == batch and tj.get("width") == w and tj.get("height") == h:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    stage_ms = {k2: 1e3 * v / args.steps for k2, v in stage_acc.items()}
+    rows, sums = _stage_table(stage_ms, bpp, batch * npx)
+    dev_s = float(np.mean(dev_times))
+    out = {
+        "metric": "vp8l_encode_megapixels_per_sec", "value": value, "unit": "MP/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "batch of %d synthetic %dx%d RGBA images, VP8L encode on one MI355X per rank "
+                               "(BASELINE configs[1]); inputs and streams resident in HBM" % (batch, w, h),
+                   "images_per_gpu": batch, "width": w, "height": h, "parallelism": "images sharded over %d GPU(s), no collective" % world},
+        "bits_per_pixel": bpp,
+        "device_ms_per_step": 1e3 * dev_s,
+        "stage_ms_per_step": stage_ms,
+        "roundtrip_verified": verify,
+        "decode": decode,
+        "decode_megapixels_per_sec": decode["value"] if decode else None,
+        "roofline": {"kernel": "k_lz77_sparse", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "launch_ms": 1e3 * lz_avg, "algorithmic_bytes_per_launch": lz_bytes * batch * npx},
+        "roofline_stages": rows,
+        "encode_bytes_per_pixel": sums,
+        "roofline_end_to_end": {"bound": "hbm", "achieved": (4.0 + bpp / 8.0) * batch * npx / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": (4.0 + bpp / 8.0) * batch * npx / dev_s / 1e9 / HBM_PEAK_GBS},
+    }
+    out["host_to_host"] = None
+    if world == 1 and not args.no_host:
+        del d_out
+        torch.cuda.empty_cache()
+        out["host_to_host"] = host_to_host(local_rank, d_in, w, h, args.host_images)
+    if world == 1 and not args.no_cpu:
+        threads = args.cpu_threads or host_threads()
+        nimg = args.cpu_images or threads
+        out["cpu_baseline"] = cpu_baseline(w, h, plan, threads, min(nimg, batch))
+    else:
+        out["cpu_baseline"] = None
+    return out
 
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = the cores this job may use)")
+    ap.add_argument("--cpu-images", type=int, default=0, help="images in the CPU-baseline sample (0 = one per thread)")
+    ap.add_argument("--host-images", type=int, default=128, help="images of the batch used for the host-memory-to-host-memory figure")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-host", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--workload", default="encode4k", choices=sorted(OTHER_WORKLOADS) + ["encode4k"],
+                    help="encode4k = BASELINE configs[1] (the headline line); the others measure configs[2..4]")
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: start one rank per GPU ourselves, before anything here touches a GPU
+        have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d but only %d device(s) visible" % (args.gpus, have))
+        rc, out0 = sharding.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        sys.stdout.write(out0)
+        sys.exit(rc)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    fn = workload_encode4k if args.workload == "encode4k" else OTHER_WORKLOADS[args.workload]
+    out = fn(args, world, rank, local_rank, dev)
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = total_px / 1e6 / elapsed
-        lz_avg = float(np.mean(lz_times))
-        achieved = LZ77_BYTES_PER_PIXEL * batch * npx / lz_avg / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "lz77_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("batch") == batch and tj.get("width") == w and tj.get("height") == h:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "vp8l_encode_megapixels_per_sec", "value": value, "unit": "MP/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic %dx%d RGBA images, VP8L encode on one MI355X per rank "
-                                   "(BASELINE configs[1]); inputs and streams resident in HBM" % (batch, w, h),
-                       "images_per_gpu": batch, "width": w, "height": h, "parallelism": "images sharded over %d GPU(s), no collective" % world},
-            "bits_per_pixel": bpp,
-            "device_ms_per_step": 1e3 * float(np.mean(dev_times)),
-            "stage_ms_per_step": {k2: 1e3 * v / args.steps for k2, v in stage_acc.items()},
-            "roundtrip_verified": verify,
-            "decode_megapixels_per_sec": decode_mps,
-            "roofline": {"kernel": "k_lz77_sparse", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launch_ms": 1e3 * lz_avg, "algorithmic_bytes_per_launch": LZ77_BYTES_PER_PIXEL * batch * npx},
-        }
-        if world == 1 and not args.no_cpu:
-            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-            nimg = args.cpu_images or threads
-            out["cpu_baseline"] = cpu_baseline(w, h, plan, threads, min(nimg, batch))
-        else:
-            out["cpu_baseline"] = None
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -77,6 +77,14 @@ int vp8l_encode_batch(int device, size_t n, const uint32_t *const *argb, const u
 int vp8l_decode_batch(int device, size_t n, const uint8_t *const *data, const size_t *len, uint32_t **argb,
                       uint32_t *width, uint32_t *height, int *status);
 
+/* The same over several devices of one node: the images are dealt out in contiguous blocks balanced by pixel count, one
+ * block per entry of `devices` (an entry may repeat), each block runs as vp8l_encode_batch / vp8l_decode_batch on its device
+ * from a host thread of its own.  Images are independent: nothing is exchanged between devices. */
+int vp8l_encode_batch_devices(const int *devices, size_t ndevices, size_t n, const uint32_t *const *argb, const uint32_t *width,
+                              const uint32_t *height, uint8_t **out, size_t *out_len, int *status);
+int vp8l_decode_batch_devices(const int *devices, size_t ndevices, size_t n, const uint8_t *const *data, const size_t *len,
+                              uint32_t **argb, uint32_t *width, uint32_t *height, int *status);
+
 /* ---- batches, device memory (pipelines, benchmarks) ---------------------------------------
  * The reference has no counterpart: it is single-image, host-only.  These are the batch forms
  * with inputs and outputs resident in HBM.  A context owns its workspace and one HIP stream;

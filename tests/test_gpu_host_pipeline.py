@@ -61,3 +61,37 @@ def test_many_chunks_few_lanes():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "pipeline ok" in r.stdout
+
+
+def test_batch_dealt_out_to_a_device_list():
+    """vp8l_encode_batch_devices / vp8l_decode_batch_devices: the device list may name one GPU several times (this box has
+    one), which runs every block on its own host thread against the same device: every image is encoded exactly once, in
+    its place, with the oracle's bytes, and decodes back."""
+    import numpy as np
+    import pytest
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    import webp_amd
+    rng = np.random.default_rng(4)
+    images = []
+    for k in range(11):
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+        images.append((O.gen_image(3 + k % 3, w, h, 50 + k, 40), w, h))
+    images.insert(4, (np.zeros(4, dtype=np.uint32), 16385, 1))   # refused by itself, inside a block
+    res = webp_amd.encode_batch(images, devices=[0, 0, 0])
+    assert res[4][0] == -2
+    streams = []
+    for k, ((st, data), (img, w, h)) in enumerate(zip(res, images)):
+        if k == 4:
+            continue
+        rc, ref = O.encode(img, w, h)
+        assert st == rc == 0 and data == ref, k
+        streams.append(data)
+    streams.insert(2, b"\0\0\0\0\x2e\0\0\0\0")
+    out = webp_amd.decode_batch(streams, devices=[0, 0])
+    assert out[2][0] == -4
+    good = [x for k, x in enumerate(images) if k != 4]
+    for (st, arr, w, h), (img, w0, h0) in zip([o for k, o in enumerate(out) if k != 2], good):
+        assert st == 0 and (w, h) == (w0, h0) and np.array_equal(arr, img)
+    with pytest.raises(webp_amd.Vp8lError):
+        webp_amd.encode_batch(images[:2], devices=[99])

@@ -251,3 +251,27 @@ def test_decoder_core_refuses_group_counts_the_stream_cannot_hold(K, index):
     rc, _, _, _ = core_decode(K, s, 4, 4)
     assert rc0 == -6      # the groups lie past the end of the stream: zeros are no code (InvalidHuffman)
     assert rc == rc0
+
+
+def test_split_by_weight_deals_contiguous_balanced_blocks(K):
+    """How vp8l_encode_batch_devices / vp8l_decode_batch_devices deal a batch out to GPUs: contiguous blocks, every item
+    exactly once, weights within one item of an equal share."""
+    K.core_split_by_weight.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    K.core_split_by_weight.restype = None
+    rng = np.random.default_rng(3)
+    for n, parts in [(0, 3), (1, 8), (5, 8), (8, 8), (256, 8), (1000, 7), (13, 1), (64, 2)]:
+        for kind in range(3):
+            w = (np.full(n, 8294400) if kind == 0 else rng.integers(1, 1 << 28, size=n) if kind == 1 else rng.integers(0, 3, size=n)).astype(np.uint64)
+            first = np.zeros(parts + 1, dtype=np.uint64)
+            K.core_split_by_weight(w.ctypes.data, n, parts, first.ctypes.data)
+            first = [int(x) for x in first]
+            assert first[0] == 0 and first[-1] == n and all(a <= b for a, b in zip(first, first[1:]))
+            if n == 0:
+                continue
+            eff = np.maximum(w, 1).astype(np.float64)
+            share = eff.sum() / parts
+            for p in range(parts):
+                got = eff[first[p]:first[p + 1]].sum()
+                assert abs(got - share) <= eff.max() + 1e-6, (n, parts, kind, p, got, share)
+            if kind == 0 and n % parts == 0:
+                assert all(first[p + 1] - first[p] == n // parts for p in range(parts))

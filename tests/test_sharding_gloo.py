@@ -58,3 +58,31 @@ def test_single_process_is_identity():
     assert sharding.global_throughput(7, 0.25) == (7, 0.25)
     assert list(sharding.shard_indices(5, 1, 0)) == [0, 1, 2, 3, 4]
     assert [len(sharding.shard_indices(10, 4, r)) for r in range(4)] == [3, 3, 2, 2]
+
+
+_LAUNCH_CHILD = """
+import os, json
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")          # RANK / WORLD_SIZE / MASTER_* come from the launcher's environment
+t = torch.tensor([float(int(os.environ["LOCAL_RANK"]) + 1)])
+dist.all_reduce(t)
+if dist.get_rank() == 0:
+    print(json.dumps({"world": dist.get_world_size(), "sum": t.item()}))
+else:
+    print("noise from another rank")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_launcher_starts_one_child_per_rank():
+    """What `bench.py --gpus N` does when it is not already under a launcher: N children with the torch.distributed
+    environment, rank 0's line returned, every rank's failure reported."""
+    import json
+    import sys
+    rc, out = sharding.launch_ranks(2, [sys.executable, "-c", _LAUNCH_CHILD], timeout=120)
+    assert rc == 0
+    assert json.loads(out.strip().splitlines()[-1]) == {"world": 2, "sum": 3.0}
+    assert "noise" not in out
+    rc, out = sharding.launch_ranks(2, [sys.executable, "-c", "import os, sys; sys.exit(3 if os.environ['RANK'] == '1' else 0)"], timeout=60)
+    assert rc == 3

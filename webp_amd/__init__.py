@@ -72,6 +72,8 @@ def lib():
         L.vp8l_free.restype = None
         L.vp8l_encode_batch.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vp8l_decode_batch.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vp8l_encode_batch_devices.argtypes = [C.c_void_p, C.c_size_t] + L.vp8l_encode_batch.argtypes[1:]
+        L.vp8l_decode_batch_devices.argtypes = [C.c_void_p, C.c_size_t] + L.vp8l_decode_batch.argtypes[1:]
         L.vp8l_encoder_create.argtypes = [C.c_int, pp_void]
         L.vp8l_encoder_destroy.argtypes = [C.c_void_p]
         L.vp8l_encoder_destroy.restype = None
@@ -114,7 +116,7 @@ EXPORTED_SYMBOLS = (
     "vp8l_decoder_last_device_seconds", "vp8l_generate_device", "vp8l_encoder_set_option",
     "vp8l_encoder_last_dense_tiles", "vp8l_decoder_set_option",
     "vp8l_decoder_last_whole_device_streams",
-    "vp8l_decoder_last_scout_streams", "vp8l_encode_device_noalloc",
+    "vp8l_decoder_last_scout_streams", "vp8l_encode_device_noalloc", "vp8l_encode_batch_devices", "vp8l_decode_batch_devices",
 )
 
 
@@ -163,8 +165,9 @@ def get_info(data):
     return w.value, h.value
 
 
-def encode_batch(images, device=-1):
-    """images: list of (argb, w, h).  Returns list of (status, bytes)."""
+def encode_batch(images, device=-1, devices=None):
+    """images: list of (argb, w, h).  Returns list of (status, bytes).  devices: a list of device numbers to deal the
+    images out to (vp8l_encode_batch_devices) instead of the one `device`."""
     n = len(images)
     arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a, _, _ in images]
     for a, (_, w, h) in zip(arrs, images):
@@ -176,7 +179,11 @@ def encode_batch(images, device=-1):
     outs = (C.c_void_p * n)()
     lens = (C.c_size_t * n)()
     status = (C.c_int * n)()
-    rc = lib().vp8l_encode_batch(device, n, ptrs, ws, hs, outs, lens, status)
+    if devices is not None:
+        devs = (C.c_int * len(devices))(*devices)
+        rc = lib().vp8l_encode_batch_devices(devs, len(devices), n, ptrs, ws, hs, outs, lens, status)
+    else:
+        rc = lib().vp8l_encode_batch(device, n, ptrs, ws, hs, outs, lens, status)
     if rc != OK:
         raise Vp8lError(rc, "vp8l_encode_batch")
     res = []
@@ -189,8 +196,8 @@ def encode_batch(images, device=-1):
     return res
 
 
-def decode_batch(streams, device=-1):
-    """streams: list of bytes.  Returns list of (status, argb | None, w, h)."""
+def decode_batch(streams, device=-1, devices=None):
+    """streams: list of bytes.  Returns list of (status, argb | None, w, h).  devices: as in encode_batch."""
     n = len(streams)
     bufs = [C.create_string_buffer(s, len(s)) for s in streams]
     ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
@@ -199,7 +206,11 @@ def decode_batch(streams, device=-1):
     ws = (C.c_uint32 * n)()
     hs = (C.c_uint32 * n)()
     status = (C.c_int * n)()
-    rc = lib().vp8l_decode_batch(device, n, ptrs, lens, outs, ws, hs, status)
+    if devices is not None:
+        devs = (C.c_int * len(devices))(*devices)
+        rc = lib().vp8l_decode_batch_devices(devs, len(devices), n, ptrs, lens, outs, ws, hs, status)
+    else:
+        rc = lib().vp8l_decode_batch(device, n, ptrs, lens, outs, ws, hs, status)
     if rc != OK:
         raise Vp8lError(rc, "vp8l_decode_batch")
     res = []

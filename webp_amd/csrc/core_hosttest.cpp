@@ -10,6 +10,7 @@
 
 #include "vp8l_dec_core.h"
 #include "vp8l_enc_core.h"
+#include "vp8l_split.h"
 
 using namespace vp8l;
 
@@ -38,6 +39,11 @@ void core_prefix_encode(uint32_t v, uint32_t *sym, uint32_t *nb, uint32_t *eb) {
 uint32_t core_dist_to_code(uint32_t xsize, uint32_t dist) { return dist_to_code(xsize, dist); }
 uint32_t core_code_to_dist(uint32_t xsize, uint32_t code) { return code_to_dist(xsize, code); }
 uint32_t core_subtract_green(uint32_t p) { return subtract_green(p); }
+// split_by_weight (vp8l_split.h): first[0..parts] into `first`
+void core_split_by_weight(const uint64_t *weight, size_t n, size_t parts, size_t *first) {
+  const std::vector<size_t> f = split_by_weight(std::vector<uint64_t>(weight, weight + n), parts);
+  for (size_t i = 0; i <= parts; i++) first[i] = f[i];
+}
 uint32_t core_add_green(uint32_t p) { return add_green(p); }
 
 // The encoder assembled from the core pieces in the order the kernels use them, with a

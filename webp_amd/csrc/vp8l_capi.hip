@@ -15,6 +15,7 @@
 #include "vp8l_amd.h"
 #include "vp8l_common.h"
 #include "vp8l_host.h"
+#include "vp8l_split.h"
 
 namespace vp8l {
 
@@ -458,4 +459,54 @@ extern "C" int vp8l_decode(const uint8_t *data, size_t len, uint32_t **argb, uin
   int status = VP8L_OK;
   const int rc = vp8l_decode_batch(-1, 1, &data, &len, argb, width, height, &status);
   return rc != VP8L_OK ? rc : status;
+}
+
+// ---- batches dealt out to several GPUs ------------------------------------------------------------
+namespace {
+// Runs part(device, first_item, count) for every device's block on a host thread of its own; the first failure wins.
+template <class Part>
+int run_on_devices(const int *devices, size_t ndevices, const std::vector<uint64_t> &weight, Part part) {
+  if (!devices || ndevices == 0) return VP8L_ERR_BAD_ARGUMENT;
+  const std::vector<size_t> first = split_by_weight(weight, ndevices);
+  std::vector<int> rcs(ndevices, VP8L_OK);
+  std::vector<std::string> texts(ndevices);
+  std::vector<std::thread> threads;
+  auto body = [&](size_t d) {
+    rcs[d] = guarded([&] { return first[d + 1] > first[d] ? part(devices[d], first[d], first[d + 1] - first[d]) : (int)VP8L_OK; });
+    if (rcs[d] != VP8L_OK) texts[d] = last_error_slot();
+  };
+  for (size_t d = 1; d < ndevices; d++) threads.emplace_back(body, d);
+  body(0);
+  for (auto &t : threads) t.join();
+  for (size_t d = 0; d < ndevices; d++)
+    if (rcs[d] != VP8L_OK) { last_error_slot() = texts[d]; return rcs[d]; }
+  return VP8L_OK;
+}
+}  // namespace
+
+extern "C" int vp8l_encode_batch_devices(const int *devices, size_t ndevices, size_t n, const uint32_t *const *argb, const uint32_t *width,
+                                         const uint32_t *height, uint8_t **out, size_t *out_len, int *status) {
+  if (!argb || !width || !height || !out || !out_len || !status) return VP8L_ERR_BAD_ARGUMENT;
+  return guarded([&] {
+    std::vector<uint64_t> weight(n);
+    for (size_t i = 0; i < n; i++) weight[i] = (uint64_t)width[i] * height[i];
+    return run_on_devices(devices, ndevices, weight, [&](int device, size_t i0, size_t m) {
+      return encode_batch_with(device, 0, m, argb + i0, width + i0, height + i0, out + i0, out_len + i0, status + i0);
+    });
+  });
+}
+
+extern "C" int vp8l_decode_batch_devices(const int *devices, size_t ndevices, size_t n, const uint8_t *const *data, const size_t *len,
+                                         uint32_t **argb, uint32_t *width, uint32_t *height, int *status) {
+  if (!data || !len || !argb || !width || !height || !status) return VP8L_ERR_BAD_ARGUMENT;
+  return guarded([&] {
+    std::vector<uint64_t> weight(n, 1);
+    for (size_t i = 0; i < n; i++) {
+      uint32_t w = 0, h = 0;
+      if (data[i] && vp8l_get_info(data[i], len[i], &w, &h) == VP8L_OK) weight[i] = (uint64_t)w * h;
+    }
+    return run_on_devices(devices, ndevices, weight, [&](int device, size_t i0, size_t m) {
+      return decode_batch_impl(device, m, data + i0, len + i0, argb + i0, width + i0, height + i0, status + i0);
+    });
+  });
 }

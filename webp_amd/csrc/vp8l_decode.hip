@@ -820,7 +820,7 @@ struct ParImage {
   uint32_t active;
   int32_t status;
   uint32_t total, xsize;
-  uint32_t pad;
+  uint32_t fold_green; // the transform to undo first is subtract green: literals are stored with green added (copies then carry it), the pass is dropped
   uint64_t P0;         // stream position of the first token, in bits
   uint32_t *dst;
   uint32_t changed[kParJumpPasses];
@@ -1025,6 +1025,7 @@ __global__ __launch_bounds__(kWgThreads, 8) void k_par_pixels(const DecImage *__
   const uint32_t hard_end = kParWindowWords * 32 - 192;  // nothing is read beyond the window
   const uint32_t P_end = par->segbase[seg + 1] < total ? first + kParSegBits + par->segentry[seg + 1] : hard_end;
   uint32_t *dst = par->dst, *srcg = par->srcg;
+  const bool fold_green = par->fold_green != 0;
   if (tid == 0) sh.status = kOk;
   int32_t status = kOk;
   WgRound r;
@@ -1035,7 +1036,7 @@ __global__ __launch_bounds__(kWgThreads, 8) void k_par_pixels(const DecImage *__
     bool expand = false;
     if (r.on && r.hop && pos < total) {  // tokens past the last pixel are not the image's
       if (pos + cnt > total) sh.status = kErrInvalidVp8l;  // a reference that runs past the end of the image
-      else if (!r.ref) { dst[pos] = val; srcg[pos] = pos | kFinalBit; }
+      else if (!r.ref) { dst[pos] = fold_green ? add_green(val) : val; srcg[pos] = pos | kFinalBit; }
       else if (val > pos) sh.status = kErrInvalidVp8l;     // a reference before the start of the image
       else expand = true;
     }
@@ -1416,6 +1417,7 @@ __global__ __launch_bounds__(kPlaceThreads) void k_par_place(const DecImage *__r
 #pragma unroll
   for (uint32_t j = 0; j < kLanesPerSeg; j++) before_part[j] = parts ? (uint32_t)slot[4 + j] : 0u;
   uint32_t *dst = par->dst, *srcg = par->srcg;
+  const bool fold_green = par->fold_green != 0;
   bool bad = false;
   auto record = [&](uint32_t i) -> uint64_t {  // token i of the segment
     if (i >= ntok) return 0ull;
@@ -1447,7 +1449,7 @@ __global__ __launch_bounds__(kPlaceThreads) void k_par_place(const DecImage *__r
     bool expand = false;
     if (cnt && pos < total) {
       if (pos + cnt > total) bad = true;        // a reference that runs past the end of the image
-      else if (!ref) { dst[pos] = val; srcg[pos] = pos | kFinalBit; }
+      else if (!ref) { dst[pos] = fold_green ? add_green(val) : val; srcg[pos] = pos | kFinalBit; }
       else if (val > pos) bad = true;           // a reference before the start of the image
       else expand = true;
     }
@@ -1566,6 +1568,11 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
           par->xsize = st.xsize;
           par->dst = st.dst;
           par->active = 1;
+          // Subtract green is undone pixel by pixel (transform.h:94-103), and a back reference copies whole pixels: if it is the
+          // first transform to undo, the segment kernels store every literal with green already added and the copies inherit it,
+          // which saves a pass over the image.  (A stream the segment kernels hand back is decoded again from the start.)
+          par->fold_green = st.nxf && st.xf[st.nxf - 1].type == 2 ? 1u : 0u;
+          if (par->fold_green) st.nxf--;
           st.status = kParPending;
         }
         __syncthreads();

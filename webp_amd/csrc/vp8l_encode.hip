@@ -563,6 +563,22 @@ __device__ __forceinline__ uint32_t dist_code_of(uint32_t xsize, uint32_t xinv, 
   return dist_to_code_inv(xsize, xinv, dist);
 }
 
+// Per-phase cycle counts of k_lz77_sparse (a measurement build only, -DVP8L_PHASE_TIMING: the first wave of every
+// workgroup adds the cycles between phase marks to g_sp_phase; read with vp8l_debug_phase_cycles).
+#ifdef VP8L_PHASE_TIMING
+__device__ unsigned long long g_sp_phase[8];
+#define VP8L_PHASE_BEGIN() unsigned long long ph_t = __builtin_readcyclecounter()
+#define VP8L_PHASE_MARK(k)                                                     \
+  do {                                                                          \
+    const unsigned long long ph_n = __builtin_readcyclecounter();               \
+    if (threadIdx.x == 0) atomicAdd(&g_sp_phase[k], ph_n - ph_t);               \
+    ph_t = ph_n;                                                                \
+  } while (0)
+#else
+#define VP8L_PHASE_BEGIN() do {} while (0)
+#define VP8L_PHASE_MARK(k) do {} while (0)
+#endif
+
 constexpr uint32_t kSpThreads = 512;
 constexpr uint32_t kSpWaves = kSpThreads / 64;
 constexpr uint32_t kSpTile = 2048;                   // positions per workgroup
@@ -613,6 +629,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   const uint64_t pos0 = imgs[img].pos0;
   const uint32_t *data = pix + pos0;
   const uint32_t lane = tid & 63, wave = tid >> 6;
+  VP8L_PHASE_BEGIN();
   for (uint32_t i = tid; i < kSpBuckets / 2; i += kSpThreads) cursor2[i] = 0;
   if (tid == 0) { s_abort = 0; s_inside = 0; s_nonempty = 0; s_heavy = 0; }
   // lo is a multiple of 4 (a and kWindow are) and the pixel array has readable slack past M: 16-byte loads
@@ -638,6 +655,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
     for (uint32_t i = tid * 4; i < W; i += kSpThreads * 4) *reinterpret_cast<uint4 *>(&px[i]) = *reinterpret_cast<const uint4 *>(data + lo + i);
   }
   __syncthreads();
+  VP8L_PHASE_MARK(0);  // window loaded (and the residual made and stored)
   const uint32_t nsrc = b - lo;  // pixels lo..b-1 can be sources
   uint32_t mixed[kSpSources / kSpThreads];  // this thread's sources tid, tid+512, ...: pixel * kSpMul
   uint32_t first_of_run = 0;         // bit k: source k*512+tid starts a run (or the window)
@@ -690,6 +708,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
       if (s0 + (uint32_t)j < W) runlen[s0 + j] = (uint16_t)(end - (s0 + j) + 1);
     }
   }
+  VP8L_PHASE_MARK(1);  // hashes, run starts, run lengths
 #pragma unroll
   for (uint32_t k = 0; k < kSpSources / kSpThreads; k++)
     if ((first_of_run >> k) & 1u) {
@@ -697,6 +716,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
       atomicAdd(&cursor2[hb >> 1], 1u << (16 * (hb & 1u)));
     }
   __syncthreads();
+  VP8L_PHASE_MARK(2);  // bucket counts
   // exclusive scan of the bucket counts (8 per thread)
   uint32_t c[8], sum = 0, mx = 0;
 #pragma unroll
@@ -744,6 +764,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
     }
   }
   __syncthreads();
+  VP8L_PHASE_MARK(3);  // scan of the counts and scatter into the buckets
   // every thread: positions a+tid, a+tid+512, ...
   uint32_t out[kSpTile / kSpThreads];
   uint32_t spent = 0;
@@ -807,8 +828,10 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   }
   };
   if (plain) search(std::true_type{}); else search(std::false_type{});
+  VP8L_PHASE_MARK(4);  // the search (first wave's share; the workgroup ends with its slowest wave)
   if (over) s_abort = 1;
   __syncthreads();
+  VP8L_PHASE_MARK(5);  // waiting for the other waves
   if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
 #pragma unroll
   for (uint32_t k = 0; k < kSpTile / kSpThreads; k++) {
@@ -818,6 +841,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
       adv[pos0 + p] = (uint8_t)((out[k] & 0xff) ? (out[k] & 0xff) : 1u);
     }
   }
+  VP8L_PHASE_MARK(6);  // results stored
 }
 
 __global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
@@ -2029,3 +2053,14 @@ extern "C" int vp8l_encode_device_noalloc(int device, void *stream, const uint32
   *out_len = (size_t)host_result[1];
   return (int)(int64_t)host_result[0];
 }
+
+#ifdef VP8L_PHASE_TIMING
+// Measurement builds only: cycles per phase of k_lz77_sparse summed over the workgroups since the last call (then cleared).
+extern "C" int vp8l_debug_phase_cycles(unsigned long long *out8) {
+  if (!hip_ok(hipDeviceSynchronize(), "sync")) return VP8L_ERR_HIP;
+  if (!hip_ok(hipMemcpyFromSymbol(out8, HIP_SYMBOL(vp8l::g_sp_phase), 8 * sizeof(unsigned long long)), "read phase counters")) return VP8L_ERR_HIP;
+  unsigned long long zero[8] = {};
+  if (!hip_ok(hipMemcpyToSymbol(HIP_SYMBOL(vp8l::g_sp_phase), zero, sizeof(zero)), "clear phase counters")) return VP8L_ERR_HIP;
+  return VP8L_OK;
+}
+#endif

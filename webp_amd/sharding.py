@@ -35,3 +35,37 @@ def global_throughput(pixels_local, seconds_local, device=None):
     dist.all_reduce(px, op=dist.ReduceOp.SUM)
     dist.all_reduce(sec, op=dist.ReduceOp.MAX)
     return int(px.item()), float(sec.item())
+
+
+def launch_ranks(n_ranks, argv, master_port=None, env_extra=None, timeout=None):
+    """Starts `argv` n_ranks times as child processes, one per GPU of this node, with the environment torch.distributed
+    expects (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT), waits for all of them and returns
+    (worst return code, rank 0's stdout).  The caller must not have touched the GPU: the children are fresh processes
+    and each one initialises its own device.  The other ranks' stdout is dropped, everybody's stderr passes through."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    if master_port is None:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        master_port = s.getsockname()[1]
+        s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(master_port))
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=sys.stderr))
+    out0 = b""
+    worst = 0
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout)
+        for p in procs:
+            rc = p.wait(timeout=timeout)
+            worst = rc if rc != 0 and worst == 0 else worst
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()   # exactly the children started here
+    return worst, out0.decode()
