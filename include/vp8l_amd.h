@@ -54,6 +54,7 @@ const char *vp8l_last_error(void); /* thread-local text of the last HIP failure 
  * VP8L_OPT_CROSS_COLOR_BITS below. */
 #define VP8L_FLAG_PREDICTOR_BITS_MASK 0xFu
 #define VP8L_FLAG_CROSS_COLOR_BITS_MASK 0xF0u
+#define VP8L_FLAG_STANDARD 0x100u /* write the standard VP8L dialect (libwebp reads it) instead of the reference's, see VP8L_OPT_STANDARD */
 int vp8l_encode(const uint32_t *argb, uint32_t width, uint32_t height, uint8_t **out, size_t *out_len,
                 uint32_t flags);
 
@@ -125,7 +126,7 @@ int vp8l_encode_device_noalloc(int device, void *stream, const uint32_t *d_argb,
 /* Options.  VP8L_OPT_MATCH_SEARCH: 0 (default) = candidate-list match search with the exhaustive
  * search as fallback for tiles with heavy duplication; 1 = exhaustive search everywhere.  Both give
  * identical streams; the option exists for verification and measurement. */
-enum { VP8L_OPT_MATCH_SEARCH = 1, VP8L_OPT_PREDICTOR_BITS = 2, VP8L_OPT_CROSS_COLOR_BITS = 3 };
+enum { VP8L_OPT_MATCH_SEARCH = 1, VP8L_OPT_PREDICTOR_BITS = 2, VP8L_OPT_CROSS_COLOR_BITS = 3, VP8L_OPT_STANDARD = 4 };
 /* VP8L_OPT_PREDICTOR_BITS: 0 (default) = the reference encoder's output (subtract green or colour indexing only,
  * vp8l.h:594-610).  2..9 = additionally apply the predictor transform (14 modes, one per tile of 2^bits pixels
  * a side, chosen per tile; the tile size grows until an image has at most 1024 tiles) in front of the same
@@ -135,6 +136,14 @@ enum { VP8L_OPT_MATCH_SEARCH = 1, VP8L_OPT_PREDICTOR_BITS = 2, VP8L_OPT_CROSS_CO
  * side three multipliers that take green out of red and green and red out of blue; the tile size grows like the
  * predictor's) after subtract green and the predictor transform, if any.  Read by the reference decoder
  * (transform.h:192-218); pays on images whose channels are correlated by factors other than one. */
+/* VP8L_OPT_STANDARD: 0 (default) = the reference's private dialect (68-symbol code-length alphabet, 6-bit fields, codes of up to 64
+ * bits, a zero chunk size: huffman_io.h:37-50,63-64, vp8l.h:461; libwebp cannot read it).  1 = the VP8L format of the WebP lossless
+ * specification: 19-symbol code-length alphabet with 4-bit count and 3-bit lengths, codes limited to 15 bits, the real chunk size in
+ * the first four bytes, the alpha-is-used bit set, and (with the predictor option) the specification's top-right rule for the last
+ * column (transform.h:137 is the reference's).  Same transforms, same match search and parse.  Wrap the stream as "RIFF", u32 size,
+ * "WEBP", "VP8L", stream (+ one zero byte if its length is odd; size = 4 + 4 + stream bytes + that byte) and libwebp decodes it.
+ * The decoder needs no option: the reference never writes anything but zero into the first 32 bits and a standard stream's chunk size
+ * is never zero, so a stream says itself which dialect it is. */
 int vp8l_encoder_set_option(vp8l_encoder *enc, int option, int value);
 /* Number of 2048-position tiles of the last call that needed the exhaustive search (and the total). */
 long vp8l_encoder_last_dense_tiles(vp8l_encoder *enc, long *total_tiles);

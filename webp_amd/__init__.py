@@ -128,7 +128,14 @@ def init():
 
 
 # ------------------------------------------------------------------ host-memory forms
-def encode(argb, width, height, predictor_bits=0, cross_color_bits=0):
+def riff_container(stream):
+    """The bytes of a .webp file around a VP8L stream (webp.h:167-173: "RIFF", size, "WEBP", "VP8L", stream), with the pad byte RIFF
+    asks for after a chunk of odd length.  libwebp reads the result if the stream is in the standard dialect."""
+    pad = len(stream) & 1
+    return b"RIFF" + (8 + len(stream) + pad).to_bytes(4, "little") + b"WEBPVP8L" + stream + b"\0" * pad
+
+
+def encode(argb, width, height, predictor_bits=0, cross_color_bits=0, standard=False):
     """VP8_LOSSLESS_ENCODER(argb, width, height).get_bit_writer() -> stream bytes (vp8l.h:585-615).
     predictor_bits 2..9 adds the predictor transform (not the reference encoder's bytes any more)."""
     a = None if argb is None else np.ascontiguousarray(argb, dtype=np.uint32)
@@ -137,7 +144,7 @@ def encode(argb, width, height, predictor_bits=0, cross_color_bits=0):
         raise Vp8lError(-1, "vp8l_encode (array holds %d pixels, %d x %d needs %d)" % (a.size, width, height, int(width) * int(height)))
     out = C.c_void_p()
     n = C.c_size_t()
-    rc = lib().vp8l_encode(a.ctypes.data if a is not None and a.size else None, width, height, C.byref(out), C.byref(n), int(predictor_bits) | (int(cross_color_bits) << 4))
+    rc = lib().vp8l_encode(a.ctypes.data if a is not None and a.size else None, width, height, C.byref(out), C.byref(n), int(predictor_bits) | (int(cross_color_bits) << 4) | (0x100 if standard else 0))
     if rc != OK:
         raise Vp8lError(rc, "vp8l_encode")
     data = C.string_at(out.value, n.value)
@@ -309,6 +316,12 @@ class Encoder:
     def set_cross_color_bits(self, bits):
         """0 (default): none.  2..9: add the cross-colour transform, tiles of 2**bits (after subtract green / predictor)."""
         rc = lib().vp8l_encoder_set_option(self._h, 3, int(bits))
+        if rc != OK:
+            raise Vp8lError(rc, "vp8l_encoder_set_option")
+
+    def set_standard(self, on):
+        """False (default): the reference's dialect.  True: the standard VP8L format (what libwebp reads)."""
+        rc = lib().vp8l_encoder_set_option(self._h, 4, 1 if on else 0)
         if rc != OK:
             raise Vp8lError(rc, "vp8l_encoder_set_option")
 

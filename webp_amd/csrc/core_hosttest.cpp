@@ -48,7 +48,7 @@ uint32_t core_add_green(uint32_t p) { return add_green(p); }
 
 // The encoder assembled from the core pieces in the order the kernels use them, with a
 // brute-force match search standing in for the match kernel.  Returns bytes or a negative status.
-long core_encode(const uint32_t *argb, uint32_t w, uint32_t h, uint8_t *out, size_t cap) {
+long core_encode_ex(const uint32_t *argb, uint32_t w, uint32_t h, uint8_t *out, size_t cap, int standard) {
   const size_t n = (size_t)w * h;
   std::vector<uint32_t> pal;
   bool has_pal = true;
@@ -85,7 +85,7 @@ long core_encode(const uint32_t *argb, uint32_t w, uint32_t h, uint8_t *out, siz
   BitSink bw;
   bw.init(words.data());
   static SubImageScratch sub;
-  int rc = write_stream_prefix(bw, w, h, pal.data(), ncolors, sub);
+  int rc = write_stream_prefix(bw, w, h, pal.data(), ncolors, sub, standard != 0);
   if (rc < 0) return rc;
   std::vector<uint32_t> len(m), dist(m);
   for (size_t p = 0; p < m; p++) {
@@ -103,16 +103,18 @@ long core_encode(const uint32_t *argb, uint32_t w, uint32_t h, uint8_t *out, siz
   for (size_t p = 0; p < m; p += len[p] ? len[p] : 1) histo_token(histo.data(), pix[p], len[p], dist[p], xsize);
   static CodeTables tables;
   static DescScratch desc;
-  rc = build_and_write_codes(bw, histo.data(), tables, desc);
+  rc = build_and_write_codes(bw, histo.data(), tables, desc, standard != 0);
   if (rc < 0) return rc;
   for (size_t p = 0; p < m; p += len[p] ? len[p] : 1)
     emit_token([&](uint32_t v, uint32_t nb) { bw.put(v, nb); }, tables, pix[p], len[p], dist[p], xsize);
   bw.flush();
   size_t bytes = (size_t)((bw.bits() + 7) / 8);
   if (bytes > cap) return -8;
+  if (standard) words[0] = (uint32_t)(bytes - 4);  // the chunk size: what follows these four bytes
   memcpy(out, words.data(), bytes);
   return (long)bytes;
 }
+long core_encode(const uint32_t *argb, uint32_t w, uint32_t h, uint8_t *out, size_t cap) { return core_encode_ex(argb, w, h, out, cap, 0); }
 
 // Sequential decoder core (header parse + entropy decode + inverse transforms on the host).
 int core_decode(const uint8_t *data, size_t len, uint32_t *argb, size_t cap_pixels, uint32_t *w, uint32_t *h) {

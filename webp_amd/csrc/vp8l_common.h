@@ -40,6 +40,37 @@ VP8L_HD int cl_order(int i) {
   return i >= 9 ? i - 3 : i == 0 ? kClZero11 : i == 1 ? kClZero138 : i == 8 ? kClRepeat : i - 2;
 }
 
+// ---- the two bitstream dialects ---------------------------------------------------------------
+// The reference writes and reads a private variant of VP8L (huffman_io.h:37-50,63-64; vp8l.h:461).  The format as
+// libwebp and the WebP lossless specification define it differs in exactly these points, and nothing else on the path:
+//                                   reference                         standard
+//   code-length alphabet            68 symbols: lengths 0..64,        19 symbols: lengths 0..15,
+//                                   65 repeat, 66 / 67 zero runs      16 repeat, 17 / 18 zero runs
+//   number of code-length codes     6 bits (count - 4)                4 bits (count - 4)
+//   each code-length-code length    6 bits (up to 32)                 3 bits (up to 7)
+//   longest code                    64 (32 in practice)               15
+//   first 32 bits of the stream     zero (never patched)              the number of bytes that follow them (RIFF chunk size)
+//   predictor, last column          top-right := left (transform.h:137)   top-right := first pixel of the current row
+//   plane code giving a distance < 1   wraps (unsigned arithmetic)    distance 1
+// A stream says which one it is: the reference never writes anything but zero into the first 32 bits, a standard
+// stream's chunk size is never zero.
+struct Dialect {
+  int ncl;            // symbols of the code-length alphabet
+  int count_bits;     // bits of (number of code-length codes - 4)
+  int len_bits;       // bits of one code-length-code length
+  int repeat, zero11, zero138;
+  int max_len;        // longest code of the five pixel codes
+  int max_cl_len;     // longest code of the code-length code
+  VP8L_HD int order(int i) const { return i >= 9 ? i - 3 : i == 0 ? zero11 : i == 1 ? zero138 : i == 8 ? repeat : i - 2; }
+};
+VP8L_HD Dialect dialect_of(bool standard) {
+  Dialect d;
+  if (standard) { d.ncl = 19; d.count_bits = 4; d.len_bits = 3; d.repeat = 16; d.zero11 = 17; d.zero138 = 18; d.max_len = 15; d.max_cl_len = 7; }
+  else { d.ncl = kNumClSyms; d.count_bits = kClCountBits; d.len_bits = kClLenBits; d.repeat = kClRepeat; d.zero11 = kClZero11; d.zero138 = kClZero138;
+         d.max_len = kMaxCodeLen; d.max_cl_len = kMaxClCodeLen; }
+  return d;
+}
+
 // ---- pixels (webp/vp8l/transform.cpp:8-19) -------------------------------------------------
 VP8L_HD uint32_t px_add(uint32_t a, uint32_t b) {
   const uint32_t ag = (a & 0xff00ff00u) + (b & 0xff00ff00u);
@@ -120,7 +151,7 @@ VP8L_HD uint32_t dist_inverse(uint32_t xsize) { return xsize >= 2 ? (uint32_t)((
 // lz77.cpp:20-35 / :59-70 in uint32 arithmetic like the reference (a negative dx with a small
 // dy*xsize wraps to a huge distance; it is not clamped to 1).  The table is the inverse of the
 // one in dist_to_code: entry (code-1) = dy*16 + (8 - dx).
-VP8L_HD uint32_t code_to_dist(uint32_t xsize, uint32_t code) {
+VP8L_HD uint32_t code_to_dist(uint32_t xsize, uint32_t code, bool standard = false) {
   constexpr uint8_t inv[120] = {
       0x18, 0x07, 0x17, 0x19, 0x28, 0x06, 0x27, 0x29, 0x16, 0x1a, 0x26, 0x2a, 0x38, 0x05, 0x37, 0x39,
       0x15, 0x1b, 0x36, 0x3a, 0x25, 0x2b, 0x48, 0x04, 0x47, 0x49, 0x14, 0x1c, 0x35, 0x3b, 0x46, 0x4a,
@@ -133,6 +164,7 @@ VP8L_HD uint32_t code_to_dist(uint32_t xsize, uint32_t code) {
   if (code <= 120) {
     const uint32_t e = inv[code - 1];
     const uint32_t d = (uint32_t)(8 - (int32_t)(e & 15)) + (e >> 4) * xsize;
+    if (standard && (int32_t)d < 1) return 1;  // signed arithmetic there: a plane code that points at or before the pixel itself means distance 1
     return d >= 1 ? d : 1;
   }
   return code - 120;

@@ -188,6 +188,8 @@ enum : uint32_t {
 struct XformRec {
   uint32_t type, bits, xsize, ysize;
   uint64_t data_off;  // offset of the tile data / palette in the aux buffer (uint32 units)
+  uint32_t img_w;     // width of the image the transform works on: the image's, or (standard dialect, after a colour-indexing
+  uint32_t pad;       // transform that bundles pixels) the bundled width; the reference always uses the image's (vp8l.h:117-126)
 };
 
 // What reading one code needs (huffman_io.h:92-195): the code-length code and the lengths being assembled.
@@ -214,6 +216,7 @@ struct DecState {
   uint32_t cnt;
   // image level
   uint32_t w, h, nxf, seen, cix, main_cache_bits;
+  uint32_t standard;      // the stream is in the standard dialect (its first 32 bits, the chunk size, are not zero)
   XformRec xf[4];
   uint64_t aux_used;
   // the coded image being read
@@ -266,6 +269,7 @@ VP8L_HD void dec_init(DecState &st, const uint8_t *data, uint64_t len, uint32_t 
   st.groups = groups1; st.groups1 = groups1; st.groups_multi = groups_multi; st.multi_cap = multi_cap;
   st.bytepos = 0; st.buf = 0; st.cnt = 0;
   st.w = st.h = st.nxf = st.seen = st.cix = st.main_cache_bits = 0;
+  st.standard = 0;
   st.aux_used = 0;
   st.phase = kPhStart; st.after = kPhDone;
   st.status = kOk; st.need_groups = 0;
@@ -281,13 +285,14 @@ VP8L_HD int read_code(BitSrc &br, int alphabet, HuffTable &t, uint16_t *sorted, 
     return build_simple(t, sorted + t.sorted_off, nsym, s0, s1, alphabet);
   }
   DecTableScratch &sc = *st.tsc;
-  uint8_t *cl_len = sc.lengths;  // first used for the 68 code-length-code lengths
+  const Dialect dl = dialect_of(st.standard != 0);
+  uint8_t *cl_len = sc.lengths;  // first used for the code-length-code lengths
   for (int i = 0; i < kNumClSyms; i++) cl_len[i] = 0;
-  const uint32_t ncodes = br.get(kClCountBits) + 4;
-  if (ncodes > (uint32_t)kNumClSyms) return kErrInvalidHuffman;
-  for (uint32_t i = 0; i < ncodes; i++) cl_len[cl_order((int)i)] = (uint8_t)br.get(kClLenBits);
+  const uint32_t ncodes = br.get((uint32_t)dl.count_bits) + 4;
+  if (ncodes > (uint32_t)dl.ncl) return kErrInvalidHuffman;
+  for (uint32_t i = 0; i < ncodes; i++) cl_len[dl.order((int)i)] = (uint8_t)br.get((uint32_t)dl.len_bits);
   sc.cl.sorted_off = 0;
-  int rc = build_table(sc.cl, sc.cl_sorted, cl_len, kNumClSyms, sc.ts);
+  int rc = build_table(sc.cl, sc.cl_sorted, cl_len, dl.ncl, sc.ts);
   if (rc < 0) return rc;
   uint32_t max_symbol;
   if (br.get(1)) {
@@ -303,14 +308,14 @@ VP8L_HD int read_code(BitSrc &br, int alphabet, HuffTable &t, uint16_t *sorted, 
   while (sym < alphabet) {
     if (max_symbol-- == 0) break;
     const uint32_t c = read_sym(br, sc.cl, sc.cl_sorted);
-    if (c < (uint32_t)kClRepeat) {
+    if (c < (uint32_t)dl.repeat) {
       lengths[sym++] = (uint8_t)c;
       if (c) prev = (int)c;
     } else {
       int reps;
       int v = 0;
-      if (c == (uint32_t)kClRepeat) { reps = (int)br.get(2) + 3; v = prev; }
-      else if (c == (uint32_t)kClZero11) reps = (int)br.get(3) + 3;
+      if (c == (uint32_t)dl.repeat) { reps = (int)br.get(2) + 3; v = prev; }
+      else if (c == (uint32_t)dl.zero11) reps = (int)br.get(3) + 3;
       else reps = (int)br.get(7) + 11;
       if (sym + reps > alphabet) return kErrInvalidHuffman;
       for (int i = 0; i < reps; i++) lengths[sym++] = (uint8_t)v;
@@ -388,7 +393,7 @@ VP8L_HD uint32_t decode_pixels(DecState &st, BitSrc &br, const DecAccel &acc) {
       const uint32_t length = base + br.get(nb);
       prefix_decode_base(read_sym(br, g->t[kDist], g->sorted), base, nb);
       const uint32_t dcode = base + br.get(nb);
-      const uint32_t dist = code_to_dist(xsize, dcode);
+      const uint32_t dist = code_to_dist(xsize, dcode, st.standard != 0);
       // The reference copies without checking (vp8l.h:298-300); a reference before the start
       // or past the end of the image is reported instead of reading/writing out of bounds.
       if (dist > fill || fill + length > total) { st.status = kErrInvalidVp8l; rc = kPxFail; break; }
@@ -432,7 +437,7 @@ VP8L_HD uint32_t dec_step(DecState &st, const DecAccel &acc = DecAccel()) {
     if (acc.on && !st.win_final && st.phase != kPhDone && br.bytepos + kWinPhaseSlack > br.win_hi) { VP8L_SAVE_BR(); return kEvRefill; }
     switch (st.phase) {
       case kPhStart: {  // ReadInfo vp8l.h:83-94
-        (void)br.get(32);
+        st.standard = br.get(32) != 0 ? 1u : 0u;  // the reference ignores these bits (vp8l.h:85) and never writes anything but zero there
         if (br.get(8) != 0x2f) VP8L_FAIL(kErrUnsupportedVp8);
         const uint32_t w = br.get(14) + 1, h = br.get(14) + 1;
         (void)br.get(1);
@@ -451,10 +456,11 @@ VP8L_HD uint32_t dec_step(DecState &st, const DecAccel &acc = DecAccel()) {
         if (st.seen & (1u << type)) VP8L_FAIL(kErrInvalidVp8l);
         st.seen |= 1u << type;
         XformRec &x = st.xf[st.nxf++];
-        x.type = type; x.bits = 0; x.xsize = 0; x.ysize = 0; x.data_off = 0;
+        x.type = type; x.bits = 0; x.xsize = 0; x.ysize = 0; x.data_off = 0; x.pad = 0;
+        x.img_w = st.standard && st.cix ? st.cix : st.w;
         if (type == 0 || type == 1) {
           x.bits = br.get(3) + 2;
-          x.xsize = (uint32_t)div_round_up(st.w, x.bits);
+          x.xsize = (uint32_t)div_round_up(x.img_w, x.bits);
           x.ysize = (uint32_t)div_round_up(st.h, x.bits);
           if (!aux_alloc(st, (uint64_t)x.xsize * x.ysize, x.data_off)) VP8L_FAIL(kErrWorkspace);
           begin_sub_image(st, st.aux + x.data_off, x.xsize, x.ysize, kPhXform);
@@ -683,22 +689,26 @@ inline int host_decode(const uint8_t *data, size_t len, uint32_t *argb, size_t c
       if (x.type == 2) {
         for (size_t i = 0; i < (size_t)w * h; i++) argb[i] = add_green(argb[i]);
       } else if (x.type == 1) {
+        const uint32_t tw = x.img_w;
         for (uint32_t y = 0; y < h; y++)
-          for (uint32_t xx = 0; xx < w; xx++)
-            argb[(size_t)y * w + xx] = inverse_cross_color(argb[(size_t)y * w + xx], td[(y >> x.bits) * x.xsize + (xx >> x.bits)]);
+          for (uint32_t xx = 0; xx < tw; xx++)
+            argb[(size_t)y * tw + xx] = inverse_cross_color(argb[(size_t)y * tw + xx], td[(y >> x.bits) * x.xsize + (xx >> x.bits)]);
       } else if (x.type == 0) {
+        const uint32_t tw = x.img_w;
         for (uint32_t y = 0; y < h && status == kOk; y++)
-          for (uint32_t xx = 0; xx < w; xx++) {
-            const size_t i = (size_t)y * w + xx;
+          for (uint32_t xx = 0; xx < tw; xx++) {
+            const size_t i = (size_t)y * tw + xx;
             uint32_t P;
             if (xx == 0 && y == 0) P = 0xff000000u;
-            else if (xx == 0) P = argb[i - w];
+            else if (xx == 0) P = argb[i - tw];
             else if (y == 0) P = argb[i - 1];
             else {
               const uint32_t mode = (td[(y >> x.bits) * x.xsize + (xx >> x.bits)] >> 8) & 0xff;
               if (mode > 13) { status = kErrInvalidVp8l; break; }
               const uint32_t L = argb[i - 1];
-              P = predict(mode, L, argb[i - w], xx == w - 1 ? L : argb[i - w + 1], argb[i - w - 1]);
+              // last column: the reference takes the left pixel (transform.h:137), the standard the next pixel in memory, which is
+              // the first pixel of the current row
+              P = predict(mode, L, argb[i - tw], xx == tw - 1 && !st->standard ? L : argb[i - tw + 1], argb[i - tw - 1]);
             }
             argb[i] = px_add(argb[i], P);
           }

@@ -40,6 +40,8 @@ struct DecResult {  // device-written
   uint32_t need_groups;
   uint32_t nxf;
   uint32_t pad;
+  uint32_t standard;  // the stream's dialect (the predictor's rule for the last column depends on it)
+  uint32_t pad2;
   XformRec xf[4];
 };
 
@@ -163,7 +165,7 @@ __device__ __noinline__ void wave_decode_pixels(VP8L_LDS DecState *st_, const VP
       __syncthreads();
     }
   }
-  const uint32_t total = uni((uint32_t)st.total), xsize = uni(st.xsize);
+  const uint32_t total = uni((uint32_t)st.total), xsize = uni(st.xsize | (st.standard << 31));  // bit 31: the dialect, for the distance codes
   uint32_t *dst = st.dst;
   const VP8L_LDS uint16_t *lutG = g.t[kGreen].lut, *lutR = g.t[kRed].lut, *lutB = g.t[kBlue].lut, *lutA = g.t[kAlpha].lut;
   uint32_t fill = 0, flushed = 0;  // flushed: multiple of 64, everything before it is in HBM
@@ -222,7 +224,7 @@ __device__ __noinline__ void wave_decode_pixels(VP8L_LDS DecState *st_, const VP
       prefix_decode_base(wb_sym(b, g.t[kDist], g.sorted, lane), base, nb);  // 32 + 10 + 32 bits at most so far
       wb_refill(b, win, im, lane);
       const uint32_t dcode = base + wb_get(b, nb);
-      const uint32_t dist = code_to_dist(xsize, dcode);
+      const uint32_t dist = code_to_dist(xsize & 0x7fffffffu, dcode, (xsize >> 31) != 0);
       // The reference copies without checking (vp8l.h:298-300); a reference before the start
       // or past the end of the image is reported instead of reading/writing out of bounds.
       if (dist > fill || length > total - fill) { status = kErrInvalidVp8l; break; }
@@ -335,6 +337,7 @@ __global__ __launch_bounds__(64) void k_decode_entropy(const DecImage *__restric
     r.status = st.status;
     r.need_groups = st.need_groups;
     r.nxf = st.nxf;
+    r.standard = st.standard;
     for (uint32_t k = 0; k < 4; k++) r.xf[k] = st.xf[k];
   }
 }
@@ -480,7 +483,7 @@ __device__ __forceinline__ void wg_token(uint64_t w, const VP8L_LDS GroupTables 
     const uint32_t dcode = base + (nb ? (uint32_t)(w >> n) & ((1u << nb) - 1u) : 0u);
     n += nb;
     if (length > kWgMaxLen) return;
-    if (kValue) val = code_to_dist(xsize, dcode);  // else only the token's bits and pixels are wanted
+    if (kValue) val = code_to_dist(xsize & 0x7fffffffu, dcode, (xsize >> 31) != 0);  // else only the token's bits and pixels are wanted
     cnt = length;
     ref = true;
     hop = n;
@@ -495,7 +498,7 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, const VP8L
   const uint32_t lane = tid & 63, wave = tid >> 6;
   constexpr uint32_t kMask = kWgRing - 1;
   uint64_t P = st.bytepos * 8 - st.cnt;  // position in the stream, in bits
-  const uint32_t total = (uint32_t)st.total, xsize = st.xsize;
+  const uint32_t total = (uint32_t)st.total, xsize = st.xsize | (st.standard << 31);  // bit 31: the dialect, for the distance codes
   uint32_t *dst = st.dst;
   wg_prepare_long(sh, g, tid);
   uint32_t fill = 0, flushed = 0;  // flushed: multiple of 64, everything before it is in HBM
@@ -704,7 +707,7 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, const VP8L
           const uint32_t length = base + wb_get(b, nb);
           prefix_decode_base(wb_sym(b, g.t[kDist], sorted, lane), base, nb);
           const uint32_t dcode = base + wb_get(b, nb);
-          const uint32_t dist = code_to_dist(xsize, dcode);
+          const uint32_t dist = code_to_dist(xsize & 0x7fffffffu, dcode, (xsize >> 31) != 0);
           if (dist > fill || length > total - fill) {
             rc = kErrInvalidVp8l;
           } else {
@@ -1565,7 +1568,7 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
         if (tid == 0) {
           par->P0 = st.bytepos * 8 - st.cnt;
           par->total = (uint32_t)st.total;
-          par->xsize = st.xsize;
+          par->xsize = st.xsize | (st.standard << 31);  // bit 31: the dialect, for the distance codes
           par->dst = st.dst;
           par->active = 1;
           // Subtract green is undone pixel by pixel (transform.h:94-103), and a back reference copies whole pixels: if it is the
@@ -1605,6 +1608,7 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
     r.status = st.status;
     r.need_groups = st.need_groups;
     r.nxf = st.nxf;
+    r.standard = st.standard;
     for (uint32_t k = 0; k < 4; k++) r.xf[k] = st.xf[k];
   }
 }
@@ -1671,7 +1675,8 @@ __device__ __forceinline__ void inverse_pointwise_unit(const DecImage *__restric
     for (uint32_t k = 0; k < kUnit / 256; k++) {
       const uint64_t p = p0 + k * 256 + tid;
       if (p >= npx) break;
-      const uint32_t y = (uint32_t)(p / im.w), xx = (uint32_t)(p - (uint64_t)y * im.w);
+      const uint32_t y = (uint32_t)(p / x.img_w), xx = (uint32_t)(p - (uint64_t)y * x.img_w);
+      if (y >= im.h) break;
       im.out[p] = inverse_cross_color(im.out[p], td[(y >> x.bits) * x.xsize + (xx >> x.bits)]);
     }
   } else {  // transform.h:59-87; only `width` pixels per row are produced (the reference overruns the row)
@@ -1719,7 +1724,8 @@ __global__ __launch_bounds__(kPredRows) void k_inverse_predictor(const DecImage 
   XformRec xf;
   if (!pass_transform(res[img], pass, xf) || xf.type != 0) return;
   const DecImage im = imgs[img];
-  const uint32_t w = im.w, h = im.h, bits = xf.bits, tmask = (1u << bits) - 1u;
+  const uint32_t w = xf.img_w, h = im.h, bits = xf.bits, tmask = (1u << bits) - 1u;
+  const bool standard = res[img].standard != 0;
   const uint32_t *modes = im.aux + xf.data_off;
   uint32_t *out = im.out;
   bool bad = false;
@@ -1729,7 +1735,7 @@ __global__ __launch_bounds__(kPredRows) void k_inverse_predictor(const DecImage 
     uint32_t *row = out + (uint64_t)(live ? y : 0) * w;
     const uint32_t *up = out + (uint64_t)(y0 ? y0 - 1 : 0) * w;  // thread 0 of a later band: the last row of the band before
     const uint32_t *mrow = modes + (live ? (y >> bits) : 0u) * xf.xsize;
-    uint32_t L = 0, T = 0, TL = 0;
+    uint32_t L = 0, T = 0, TL = 0, row0 = 0;  // row0: the row's first pixel (the standard dialect's top-right of the last column)
     if (r == 0 && y0) T = up[0];
     const uint32_t rows_here = h - y0 < kPredRows ? h - y0 : kPredRows;
     const uint32_t steps = w + 2 * (rows_here - 1);
@@ -1770,7 +1776,7 @@ __global__ __launch_bounds__(kPredRows) void k_inverse_predictor(const DecImage 
           T = above;
         } else {
           if (((uint32_t)x & tmask) == 0) mode = mode_next;
-          const uint32_t TR = (x == (int)w - 1) ? L : above;  // transform.h:137
+          const uint32_t TR = (x == (int)w - 1) ? (standard ? row0 : L) : above;  // transform.h:137; standard: the next pixel in memory
           if (mode > 13) bad = true;
           P = predict(mode, L, T, TR, TL);
           TL = T;
@@ -1779,6 +1785,7 @@ __global__ __launch_bounds__(kPredRows) void k_inverse_predictor(const DecImage 
         // the mode of the next tile, fetched when this one starts
         if (((uint32_t)x & tmask) == 0 && (((uint32_t)x >> bits) + 1) < xf.xsize) mode_next = (mrow[((uint32_t)x >> bits) + 1] >> 8) & 0xff;
         L = px_add(ring[t & 7u][r], P);
+        if (x == 0) row0 = L;
         row[x] = L;
         hand[t & 1u][r + 1] = L;
       }
@@ -1808,7 +1815,8 @@ __global__ __launch_bounds__(64) void k_inverse_predictor_bands(const DecImage *
   XformRec xf;
   if (!pass_transform(res[img], pass, xf) || xf.type != 0) return;
   const DecImage im = imgs[img];
-  const uint32_t w = im.w, h = im.h, bits = xf.bits, tmask = (1u << bits) - 1u;
+  const uint32_t w = xf.img_w, h = im.h, bits = xf.bits, tmask = (1u << bits) - 1u;
+  const bool standard = res[img].standard != 0;
   const uint32_t y0 = band * kBandRows;
   if (y0 >= h) return;
   const uint32_t *modes = im.aux + xf.data_off;
@@ -1846,7 +1854,7 @@ __global__ __launch_bounds__(64) void k_inverse_predictor_bands(const DecImage *
     upn = 0;
     if (y0 && !late && r < 8 && t8 + r + 1 < w) upn = __hip_atomic_load(&up[t8 + r + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  uint32_t L = 0, T = 0, TL = 0, made = 0, upcur = 0;
+  uint32_t L = 0, T = 0, TL = 0, made = 0, upcur = 0, row0 = 0;
   if (y0) {
     wait_for(1);
     if (!late) T = __hip_atomic_load(&up[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // used by lane 0 only
@@ -1884,7 +1892,7 @@ __global__ __launch_bounds__(64) void k_inverse_predictor_bands(const DecImage *
         T = above;
       } else {
         if (((uint32_t)x & tmask) == 0) mode = mode_next;
-        const uint32_t TR = (x == (int)w - 1) ? L : above;  // transform.h:137
+        const uint32_t TR = (x == (int)w - 1) ? (standard ? row0 : L) : above;  // transform.h:137; standard: the next pixel in memory
         if (mode > 13) bad = true;
         P = predict(mode, L, T, TR, TL);
         TL = T;
@@ -1892,6 +1900,7 @@ __global__ __launch_bounds__(64) void k_inverse_predictor_bands(const DecImage *
       }
       if (((uint32_t)x & tmask) == 0 && (((uint32_t)x >> bits) + 1) < xf.xsize) mode_next = (mrow[((uint32_t)x >> bits) + 1] >> 8) & 0xff;
       L = px_add(ring[t & 7u][r], P);
+      if (x == 0) row0 = L;
       if (r == rows_here - 1) __hip_atomic_store(&row[x], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the band below reads this row
       else row[x] = L;
       made = L;

@@ -120,6 +120,28 @@ VP8L_HD int huffman_lengths(const uint32_t *histo, int n, int max_len, uint8_t *
   return used;
 }
 
+// Standard dialect: codes of at most `limit` bits (15, or 7 for the code-length code).  The reference has no such step (its
+// dialect allows 64); any complete prefix code within the limit is a valid stream there, so the usual remedy is used: counts
+// below a floor are raised to the floor and the code is built again, the floor doubling until the longest code fits.  The
+// floor starts where a code of `limit` bits becomes possible at all (total / 2^limit).  `histo` is changed in place.
+VP8L_HD int huffman_lengths_limited(uint32_t *histo, int n, int limit, uint8_t *lengths, HuffScratch &s, int presorted_used = -1) {
+  int used = huffman_lengths(histo, n, limit, lengths, s, presorted_used);
+  if (used != -3) return used;
+  uint64_t total = 0;
+  for (int i = 0; i < n; i++) total += histo[i];
+  uint32_t floor_count = 2;
+  while (((uint64_t)floor_count << limit) < total) floor_count <<= 1;
+  floor_count >>= 1;
+  if (floor_count < 2) floor_count = 2;
+  for (;;) {
+    for (int i = 0; i < n; i++)
+      if (histo[i] && histo[i] < floor_count) histo[i] = floor_count;
+    used = huffman_lengths(histo, n, limit, lengths, s);
+    if (used != -3 || floor_count >= 0x40000000u) return used;
+    floor_count <<= 1;
+  }
+}
+
 // Canonical codes in symbol order (huffman_coding.cpp:8-49), bit-reversed for the LSB-first
 // writer (huffman_coding.h:356-363,415-418).  Lengths <= 32.
 VP8L_HD void canonical_reversed_codes(const uint8_t *lengths, int n, uint32_t *codes) {
@@ -144,7 +166,7 @@ struct DescScratch {
 };
 
 // Run-length form of a code-length array (huffman_io.h:226-326).
-VP8L_HD int rle_code_lengths(const uint8_t *lengths, int n, uint8_t *sym, uint8_t *extra) {
+VP8L_HD int rle_code_lengths(const uint8_t *lengths, int n, uint8_t *sym, uint8_t *extra, const Dialect &dl = dialect_of(false)) {
   int k = 0, prev = 8;
   int i = 0;
   while (i < n) {
@@ -154,14 +176,14 @@ VP8L_HD int rle_code_lengths(const uint8_t *lengths, int n, uint8_t *sym, uint8_
     int reps = j - i;
     i = j;
     if (v == 0) {
-      while (reps >= 139) { sym[k] = kClZero138; extra[k++] = 127; reps -= 138; }
-      if (reps >= 11) { sym[k] = kClZero138; extra[k++] = (uint8_t)(reps - 11); }
-      else if (reps >= 3) { sym[k] = kClZero11; extra[k++] = (uint8_t)(reps - 3); }
+      while (reps >= 139) { sym[k] = (uint8_t)dl.zero138; extra[k++] = 127; reps -= 138; }
+      if (reps >= 11) { sym[k] = (uint8_t)dl.zero138; extra[k++] = (uint8_t)(reps - 11); }
+      else if (reps >= 3) { sym[k] = (uint8_t)dl.zero11; extra[k++] = (uint8_t)(reps - 3); }
       else for (; reps > 0; reps--) { sym[k] = 0; extra[k++] = 0; }
     } else {
       if (prev != v) { sym[k] = (uint8_t)v; extra[k++] = 0; reps--; }
-      while (reps >= 7) { sym[k] = kClRepeat; extra[k++] = 3; reps -= 6; }
-      if (reps >= 3) { sym[k] = kClRepeat; extra[k++] = (uint8_t)(reps - 3); }
+      while (reps >= 7) { sym[k] = (uint8_t)dl.repeat; extra[k++] = 3; reps -= 6; }
+      if (reps >= 3) { sym[k] = (uint8_t)dl.repeat; extra[k++] = (uint8_t)(reps - 3); }
       else for (; reps > 0; reps--) { sym[k] = (uint8_t)v; extra[k++] = 0; }
       prev = v;
     }
@@ -169,8 +191,10 @@ VP8L_HD int rle_code_lengths(const uint8_t *lengths, int n, uint8_t *sym, uint8_
   return k;
 }
 
-// One code description (huffman_io.h:331-410).  Returns 0 or -3.
-VP8L_HD int write_code_desc(BitSink &bw, const uint8_t *lengths, int n, DescScratch &s) {
+// One code description (huffman_io.h:331-410).  Returns 0 or -3.  standard: the same description in the standard
+// dialect's code-length alphabet and field widths.
+VP8L_HD int write_code_desc(BitSink &bw, const uint8_t *lengths, int n, DescScratch &s, bool standard = false) {
+  const Dialect dl = dialect_of(standard);
   int count = 0;
   uint32_t first[2] = {0, 0};
   for (int i = 0; i < n && count <= 2; i++)
@@ -185,26 +209,28 @@ VP8L_HD int write_code_desc(BitSink &bw, const uint8_t *lengths, int n, DescScra
     return 0;
   }
   bw.put(0, 1);
-  const int nitems = rle_code_lengths(lengths, n, s.rle_sym, s.rle_extra);
+  const int nitems = rle_code_lengths(lengths, n, s.rle_sym, s.rle_extra, dl);
   for (int i = 0; i < kNumClSyms; i++) s.cl_histo[i] = 0;
   for (int i = 0; i < nitems; i++) s.cl_histo[s.rle_sym[i]]++;
-  const int used = huffman_lengths(s.cl_histo, kNumClSyms, kMaxClCodeLen, s.cl_len, s.huff);
+  const int used = standard ? huffman_lengths_limited(s.cl_histo, dl.ncl, dl.max_cl_len, s.cl_len, s.huff)
+                            : huffman_lengths(s.cl_histo, dl.ncl, dl.max_cl_len, s.cl_len, s.huff);
   if (used < 0) return used;
-  canonical_reversed_codes(s.cl_len, kNumClSyms, s.cl_code);
-  int nwrite = kNumClSyms;
-  while (nwrite > 4 && s.cl_len[cl_order(nwrite - 1)] == 0) nwrite--;
-  bw.put((uint32_t)(nwrite - 4), kClCountBits);
-  for (int i = 0; i < nwrite; i++) bw.put(s.cl_len[cl_order(i)], kClLenBits);
+  canonical_reversed_codes(s.cl_len, dl.ncl, s.cl_code);
+  int nwrite = dl.ncl;
+  while (nwrite > 4 && s.cl_len[dl.order(nwrite - 1)] == 0) nwrite--;
+  bw.put((uint32_t)(nwrite - 4), (uint32_t)dl.count_bits);
+  for (int i = 0; i < nwrite; i++) bw.put(s.cl_len[dl.order(i)], (uint32_t)dl.len_bits);
   bw.put(0, 1);  // no max_symbol (huffman_io.h:358)
   for (int i = 0; i < nitems; i++) {
     const int sy = s.rle_sym[i];
     // With a single used code-length symbol its length is 1 and one 0 bit per item is written,
     // although the reference reader consumes none (huffman_io.h:363 vs huffman_coding.h:207-214):
-    // kept byte-identical; the reference cannot decode such a stream either.
-    bw.put(s.cl_code[sy], s.cl_len[sy]);
-    if (sy == kClRepeat) bw.put(s.rle_extra[i], 2);
-    else if (sy == kClZero11) bw.put(s.rle_extra[i], 3);
-    else if (sy == kClZero138) bw.put(s.rle_extra[i], 7);
+    // kept byte-identical; the reference cannot decode such a stream either.  A standard reader takes no bits for a
+    // one-symbol code either, and there none are written.
+    if (!(standard && used == 1)) bw.put(s.cl_code[sy], s.cl_len[sy]);
+    if (sy == dl.repeat) bw.put(s.rle_extra[i], 2);
+    else if (sy == dl.zero11) bw.put(s.rle_extra[i], 3);
+    else if (sy == dl.zero138) bw.put(s.rle_extra[i], 7);
   }
   return 0;
 }
@@ -218,16 +244,17 @@ struct CodeTables {
 
 // Builds the five codes from the five histograms and writes their descriptions
 // (vp8l.h:536-540).  Returns 0 or -3.
-VP8L_HD int build_and_write_codes(BitSink &bw, const uint32_t *histo /*[5*kCodeStride]*/, CodeTables &t,
-                                  DescScratch &s) {
+VP8L_HD int build_and_write_codes(BitSink &bw, uint32_t *histo /*[5*kCodeStride]; changed in the standard dialect*/, CodeTables &t,
+                                  DescScratch &s, bool standard = false) {
   for (int c = 0; c < kNumCodes; c++) {
     const int n = alphabet_size(c);
     uint8_t *len = t.len + c * kCodeStride;
-    const int used = huffman_lengths(histo + c * kCodeStride, n, kMaxCodeLen, len, s.huff);
+    const int used = standard ? huffman_lengths_limited(histo + c * kCodeStride, n, dialect_of(true).max_len, len, s.huff)
+                              : huffman_lengths(histo + c * kCodeStride, n, kMaxCodeLen, len, s.huff);
     if (used < 0) return used;
     t.used[c] = (uint32_t)used;
     canonical_reversed_codes(len, n, t.code + c * kCodeStride);
-    const int rc = write_code_desc(bw, len, n, s);
+    const int rc = write_code_desc(bw, len, n, s, standard);
     if (rc < 0) return rc;
   }
   return 0;
@@ -317,23 +344,25 @@ VP8L_HD void small_write_tokens(BitSink &bw, const uint32_t *data, int n, uint32
   for (int p = 0; p < n; p += s.lz.len[p] ? s.lz.len[p] : 1)
     emit_token([&](uint32_t v, uint32_t nb) { bw.put(v, nb); }, s.tables, data[p], s.lz.len[p], s.lz.dist[p], xsize);
 }
-VP8L_HD int write_small_coded_image(BitSink &bw, const uint32_t *data, int n, uint32_t xsize, SubImageScratch &s) {
+VP8L_HD int write_small_coded_image(BitSink &bw, const uint32_t *data, int n, uint32_t xsize, SubImageScratch &s, bool standard = false) {
   bw.put(0, 1);  // no colour cache
   small_best_matches(data, n, s.lz);
   small_histogram(data, n, xsize, s);
-  const int rc = build_and_write_codes(bw, s.histo, s.tables, s.desc);
+  const int rc = build_and_write_codes(bw, s.histo, s.tables, s.desc, standard);
   if (rc < 0) return rc;
   small_write_tokens(bw, data, n, xsize, s);
   return 0;
 }
 
 // Everything in front of the main image's codes (vp8l.h:585-612, WriteTransforms :411-459).
-VP8L_HD void write_stream_head(BitSink &bw, uint32_t w, uint32_t h, uint32_t ncolors) {
+// standard: the alpha-is-used bit is set (the reference always writes 0, vp8l.h:465; standard readers may drop the alpha
+// channel when it is 0), and the first 32 bits are patched with the chunk size once the stream's length is known.
+VP8L_HD void write_stream_head(BitSink &bw, uint32_t w, uint32_t h, uint32_t ncolors, bool standard = false) {
   bw.put(0, 32);
   bw.put(0x2f, 8);
   bw.put(w - 1, 14);
   bw.put(h - 1, 14);
-  bw.put(0, 1);
+  bw.put(standard ? 1 : 0, 1);
   bw.put(0, 3);
   bw.put(1, 1);
   if (ncolors == 0) {
@@ -366,11 +395,11 @@ VP8L_HD void write_stream_tail(BitSink &bw) {
   bw.put(0, 1);
 }
 VP8L_HD int write_stream_prefix(BitSink &bw, uint32_t w, uint32_t h, const uint32_t *palette, uint32_t ncolors,
-                                SubImageScratch &s) {
-  write_stream_head(bw, w, h, ncolors);
+                                SubImageScratch &s, bool standard = false) {
+  write_stream_head(bw, w, h, ncolors, standard);
   if (ncolors) {
     palette_deltas(palette, ncolors, s.delta);
-    const int rc = write_small_coded_image(bw, s.delta, (int)ncolors, ncolors, s);
+    const int rc = write_small_coded_image(bw, s.delta, (int)ncolors, ncolors, s, standard);
     if (rc < 0) return rc;
   }
   write_stream_tail(bw);

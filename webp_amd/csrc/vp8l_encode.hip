@@ -364,7 +364,7 @@ __device__ __forceinline__ uint32_t abs_cost(uint32_t r) {  // rough bit cost of
 }
 
 __global__ __launch_bounds__(256) void k_pred_modes(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
-                                                    const uint32_t *__restrict__ pix, uint32_t *__restrict__ modes) {
+                                                    const uint32_t *__restrict__ pix, uint32_t *__restrict__ modes, uint32_t standard) {
   __shared__ uint32_t wcost[4][14];
   const uint32_t img = blockIdx.x / kSmallMax, tile = blockIdx.x % kSmallMax, tid = threadIdx.x;
   const EncState &s = st[img];
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_pred_modes(const EncImage *__restrict__
     if (x >= w || y >= h) continue;
     const uint64_t i = (uint64_t)y * w + x;
     const uint32_t cur = src[i], L = src[i - 1], T = src[i - w], TL = src[i - w - 1];
-    const uint32_t TR = x == w - 1 ? L : src[i - w + 1];
+    const uint32_t TR = x == w - 1 && !standard ? L : src[i - w + 1];  // standard dialect: the next pixel in memory (first of the current row)
 #pragma unroll
     for (int m = 0; m < 14; m++) cost[m] += abs_cost(px_sub(cur, predict((uint32_t)m, L, T, TR, TL)));
   }
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void k_pred_modes(const EncImage *__restrict__
 __global__ __launch_bounds__(256) void k_pred_residual(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                        const uint32_t *__restrict__ sb_first, uint32_t n,
                                                        const uint32_t *__restrict__ pix, const uint32_t *__restrict__ modes,
-                                                       uint32_t *__restrict__ dst) {
+                                                       uint32_t *__restrict__ dst, uint32_t standard) {
   const uint32_t unit = blockIdx.x, sb = unit / kUnitsPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   const EncState &s = st[img];
   const uint32_t M = s.M;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_pred_residual(const EncImage *__restric
     else {
       const uint32_t L = src[p - 1];
       const uint32_t mode = (mimg[(y >> bits) * s.pred_tx + (x >> bits)] >> 8) & 0xff;
-      P = predict(mode, L, src[p - w], x == w - 1 ? L : src[p - w + 1], src[p - w - 1]);
+      P = predict(mode, L, src[p - w], x == w - 1 && !standard ? L : src[p - w + 1], src[p - w - 1]);
     }
     out[p] = px_sub(cur, P);
   }
@@ -1081,15 +1081,16 @@ __device__ __forceinline__ int wave_prepare_leaves(const uint32_t *h, int n, Huf
 // The five codes of one coded image from its five histograms, by four waves: green, red, blue and alpha side
 // by side (wave 0 then adds the distance code); the sort of each is done by its wave, the joining of the tree
 // by the wave's first lane.  rc[c] < 0: that code failed (TooBigCodeLength).  Ends with a barrier.
-__device__ __forceinline__ void build_codes_4waves(const uint32_t *histo5, CodeTables &t, int *rc, HuffScratch &hs, uint32_t wave,
-                                                   uint32_t lane) {
+// standard: codes of at most 15 bits (the histogram is then changed in place, huffman_lengths_limited).
+__device__ __forceinline__ void build_codes_4waves(uint32_t *histo5, CodeTables &t, int *rc, HuffScratch &hs, uint32_t wave,
+                                                   uint32_t lane, bool standard) {
   for (uint32_t c = wave; c < (uint32_t)kNumCodes; c += 4) {
     const int nsym = alphabet_size((int)c);
-    const uint32_t *h = histo5 + c * kCodeStride;
+    uint32_t *h = histo5 + c * kCodeStride;
     uint8_t *len = t.len + c * kCodeStride;
     const int used = wave_prepare_leaves(h, nsym, hs, lane);
     if (lane == 0) {
-      const int u = huffman_lengths(h, nsym, kMaxCodeLen, len, hs, used);
+      const int u = standard ? huffman_lengths_limited(h, nsym, dialect_of(true).max_len, len, hs, used) : huffman_lengths(h, nsym, kMaxCodeLen, len, hs, used);
       rc[c] = u;
       if (u >= 0) {
         t.used[c] = (uint32_t)u;
@@ -1106,7 +1107,7 @@ __device__ __forceinline__ void build_codes_4waves(const uint32_t *histo5, CodeT
 __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
                                                         const uint32_t *__restrict__ histo, CodeTables *__restrict__ tables,
                                                         const uint32_t *__restrict__ modes, const uint32_t *__restrict__ elems,
-                                                        uint8_t *__restrict__ out) {
+                                                        uint8_t *__restrict__ out, uint32_t standard) {
   __shared__ HeaderShared sh;
   __shared__ BitSink bw;
   __shared__ int s_rc;
@@ -1118,7 +1119,7 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
   for (uint32_t i = tid; i < kMaxPalette; i += 256) sh.palette[i] = st[img].palette[i];
   if (tid == 0) {
     bw.init(reinterpret_cast<uint32_t *>(out + im.out_off));
-    write_stream_head(bw, im.w, im.h, ncolors);
+    write_stream_head(bw, im.w, im.h, ncolors, standard != 0);
     s_rc = 0;
   }
   __syncthreads();
@@ -1160,23 +1161,23 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
     __syncthreads();
     if (tid == 0) small_histogram(d, np, sub_xsize, sh.sub);
     __syncthreads();
-    build_codes_4waves(sh.sub.histo, sh.sub.tables, sh.rc, hs, wave, lane);
+    build_codes_4waves(sh.sub.histo, sh.sub.tables, sh.rc, hs, wave, lane, standard != 0);
     if (tid == 0 && s_rc == 0) {
       bw.put(0, 1);  // no colour cache
       int rc = 0;
       for (int c = 0; c < kNumCodes && rc == 0; c++)
-        rc = sh.rc[c] < 0 ? sh.rc[c] : write_code_desc(bw, sh.sub.tables.len + c * kCodeStride, alphabet_size(c), sh.sub.desc);
+        rc = sh.rc[c] < 0 ? sh.rc[c] : write_code_desc(bw, sh.sub.tables.len + c * kCodeStride, alphabet_size(c), sh.sub.desc, standard != 0);
       if (rc == 0) small_write_tokens(bw, d, np, sub_xsize, sh.sub);
       s_rc = rc;
     }
     __syncthreads();
   }
-  build_codes_4waves(sh.histo, sh.tables, sh.rc, hs, wave, lane);
+  build_codes_4waves(sh.histo, sh.tables, sh.rc, hs, wave, lane, standard != 0);
   if (tid == 0) {
     int rc = s_rc;
     if (rc == 0) write_stream_tail(bw);
     for (int c = 0; c < kNumCodes && rc == 0; c++)  // vp8l.h:536-540
-      rc = sh.rc[c] < 0 ? sh.rc[c] : write_code_desc(bw, sh.tables.len + c * kCodeStride, alphabet_size(c), sh.sub.desc);
+      rc = sh.rc[c] < 0 ? sh.rc[c] : write_code_desc(bw, sh.tables.len + c * kCodeStride, alphabet_size(c), sh.sub.desc, standard != 0);
     bw.flush();
     st[img].hdr_bits = (uint32_t)bw.bits();
     st[img].status = rc;
@@ -1269,7 +1270,7 @@ __global__ __launch_bounds__(256) void k_bitcount(const EncImage *__restrict__ i
 // all others, so no bulk clear of the output buffer is needed.
 __global__ __launch_bounds__(256) void k_scan(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
                                               const uint32_t *__restrict__ sb_first, const uint32_t *__restrict__ unit_bits,
-                                              uint64_t *__restrict__ unit_off, uint8_t *__restrict__ out) {
+                                              uint64_t *__restrict__ unit_off, uint8_t *__restrict__ out, uint32_t standard) {
   __shared__ uint32_t wsum[4];
   const uint32_t img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const EncImage im = imgs[img];
@@ -1300,6 +1301,8 @@ __global__ __launch_bounds__(256) void k_scan(const EncImage *__restrict__ imgs,
     s.total_bits = running;
     if ((running >> 5) > hdr_word) out32[running >> 5] = 0;
     if ((running + 7) / 8 + 8 > im.out_cap) s.status = VP8L_ERR_NO_MEMORY;
+    // standard dialect: the first 32 bits are the RIFF chunk size, the bytes that follow them (the reference leaves zero, vp8l.h:461)
+    if (standard) out32[0] = (uint32_t)((running + 7) / 8 - 4);
   }
 }
 
@@ -1552,6 +1555,7 @@ struct vp8l_encoder {
   bool last_pred = false;
   bool last_cross = false;
   int cross_bits = 0;  // 0 = no cross-colour transform, else requested tile bits 2..9
+  bool standard = false;  // write the standard dialect (what libwebp reads) instead of the reference's
   int pred_bits = 0;   // 0 = no predictor transform (the reference encoder's output), else requested tile bits 2..9
   // last batch
   std::vector<EncImage> imgs;
@@ -1584,7 +1588,7 @@ struct EncBuffers {
 // Clears what must start at zero and launches every kernel of the encode path for nl images that occupy sb_total
 // superblocks; imgs and sbf are already on their way on the same stream.  ev: ten events for stage times, or null.
 static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl, uint32_t sb_total, uint32_t pred, uint32_t cross,
-                                 int match_mode, uint8_t *d_out, hipEvent_t *ev) {
+                                 int match_mode, uint8_t *d_out, hipEvent_t *ev, uint32_t standard = 0) {
   bool h = true;
   h = h && hip_ok(hipMemsetAsync(B.st, 0, nl * sizeof(EncState), s), "clear state");
   h = h && hip_ok(hipMemsetAsync(B.gsets, 0xff, (size_t)nl * kSetSlots * sizeof(unsigned long long), s), "clear sets");
@@ -1599,8 +1603,8 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   mark(1);
   hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix_t);
   if (pred) {
-    hipLaunchKernelGGL(k_pred_modes, dim3(nl * kSmallMax), dim3(256), 0, s, B.imgs, B.st, B.pix_t, B.modes);
-    hipLaunchKernelGGL(k_pred_residual, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix_t, B.modes, B.pix);
+    hipLaunchKernelGGL(k_pred_modes, dim3(nl * kSmallMax), dim3(256), 0, s, B.imgs, B.st, B.pix_t, B.modes, standard);
+    hipLaunchKernelGGL(k_pred_residual, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix_t, B.modes, B.pix, standard);
   }
   if (cross) {  // on what the predictor left (in place), or on the subtract-green image
     const uint32_t *from = pred ? B.pix : B.pix_t;
@@ -1621,10 +1625,10 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   mark(4);
   hipLaunchKernelGGL(k_histogram, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.histo);
   mark(5);
-  hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.histo, B.tables, B.modes, B.elems, d_out);
+  hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.histo, B.tables, B.modes, B.elems, d_out, standard);
   mark(6);
   hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables, B.gbits, B.ubits);
-  hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.sbf, B.ubits, B.uoff, d_out);
+  hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.sbf, B.ubits, B.uoff, d_out, standard);
   mark(7);
   hipLaunchKernelGGL(k_emit, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables, B.gbits, B.uoff, d_out);
   mark(8);
@@ -1755,7 +1759,7 @@ static int vp8l_encoder_encode_device_impl(vp8l_encoder *e, size_t n, const uint
   h = h && hip_ok(hipMemcpyAsync(B.imgs, e->imgs.data(), nl * sizeof(EncImage), hipMemcpyHostToDevice, s), "upload images");
   h = h && hip_ok(hipMemcpyAsync(B.sbf, e->sb_first.data(), (nl + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s), "upload table");
   if (!h) return VP8L_ERR_HIP;
-  rc_launch = launch_encode_kernels(s, B, nl, (uint32_t)sb_total, pred, cross, e->match_mode, d_out, e->ev);
+  rc_launch = launch_encode_kernels(s, B, nl, (uint32_t)sb_total, pred, cross, e->match_mode, d_out, e->ev, e->standard ? 1u : 0u);
   if (rc_launch != VP8L_OK) return rc_launch;
   if (!hip_ok(hipMemcpyAsync(e->states.data(), st, nl * sizeof(EncState), hipMemcpyDeviceToHost, s), "download state")) return VP8L_ERR_HIP;
   if (!hip_ok(hipStreamSynchronize(s), "encode batch")) return VP8L_ERR_HIP;
@@ -1859,6 +1863,7 @@ extern "C" int vp8l_encoder_set_option(vp8l_encoder *e, int option, int value) {
   if (option == VP8L_OPT_MATCH_SEARCH && (value == 0 || value == 1)) { e->match_mode = value; return VP8L_OK; }
   if (option == VP8L_OPT_PREDICTOR_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->pred_bits = value; return VP8L_OK; }
   if (option == VP8L_OPT_CROSS_COLOR_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->cross_bits = value; return VP8L_OK; }
+  if (option == VP8L_OPT_STANDARD && (value == 0 || value == 1)) { e->standard = value != 0; return VP8L_OK; }
   return VP8L_ERR_BAD_ARGUMENT;
 }
 
