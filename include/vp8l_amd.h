@@ -54,6 +54,8 @@ const char *vp8l_last_error(void); /* thread-local text of the last HIP failure 
  * VP8L_OPT_CROSS_COLOR_BITS below. */
 #define VP8L_FLAG_PREDICTOR_BITS_MASK 0xFu
 #define VP8L_FLAG_CROSS_COLOR_BITS_MASK 0xF0u
+#define VP8L_FLAG_CACHE_BITS_MASK 0xF000u   /* (flags & mask) >> 12 = VP8L_OPT_CACHE_BITS */
+#define VP8L_FLAG_META_BITS_MASK 0xF0000u   /* (flags & mask) >> 16 = VP8L_OPT_META_BITS (with the default number of groups) */
 #define VP8L_FLAG_STANDARD 0x100u /* write the standard VP8L dialect (libwebp reads it) instead of the reference's, see VP8L_OPT_STANDARD */
 int vp8l_encode(const uint32_t *argb, uint32_t width, uint32_t height, uint8_t **out, size_t *out_len,
                 uint32_t flags);
@@ -126,7 +128,8 @@ int vp8l_encode_device_noalloc(int device, void *stream, const uint32_t *d_argb,
 /* Options.  VP8L_OPT_MATCH_SEARCH: 0 (default) = candidate-list match search with the exhaustive
  * search as fallback for tiles with heavy duplication; 1 = exhaustive search everywhere.  Both give
  * identical streams; the option exists for verification and measurement. */
-enum { VP8L_OPT_MATCH_SEARCH = 1, VP8L_OPT_PREDICTOR_BITS = 2, VP8L_OPT_CROSS_COLOR_BITS = 3, VP8L_OPT_STANDARD = 4 };
+enum { VP8L_OPT_MATCH_SEARCH = 1, VP8L_OPT_PREDICTOR_BITS = 2, VP8L_OPT_CROSS_COLOR_BITS = 3, VP8L_OPT_STANDARD = 4,
+       VP8L_OPT_CACHE_BITS = 5, VP8L_OPT_META_BITS = 6, VP8L_OPT_META_GROUPS = 7 };
 /* VP8L_OPT_PREDICTOR_BITS: 0 (default) = the reference encoder's output (subtract green or colour indexing only,
  * vp8l.h:594-610).  2..9 = additionally apply the predictor transform (14 modes, one per tile of 2^bits pixels
  * a side, chosen per tile; the tile size grows until an image has at most 1024 tiles) in front of the same
@@ -136,6 +139,13 @@ enum { VP8L_OPT_MATCH_SEARCH = 1, VP8L_OPT_PREDICTOR_BITS = 2, VP8L_OPT_CROSS_CO
  * side three multipliers that take green out of red and green and red out of blue; the tile size grows like the
  * predictor's) after subtract green and the predictor transform, if any.  Read by the reference decoder
  * (transform.h:192-218); pays on images whose channels are correlated by factors other than one. */
+/* VP8L_OPT_CACHE_BITS: 0 (default) = no colour cache, as the reference encoder writes (vp8l.h:513); 1..11 = a colour cache of 2^bits entries
+ * (read by the reference decoder: ReadColorCacheBits vp8l.h:230-241, color_cache.h:29-54): a pixel the parse codes by itself is written
+ * as its cache index when the decoder's cache holds it at that moment.
+ * VP8L_OPT_META_BITS: 0 (default) = one set of five Huffman codes for the image (vp8l.h:514); 2..9 = an entropy image with tiles of 2^bits
+ * pixels a side (the tile size grows until the image has at most 1024 tiles) that gives every tile one of VP8L_OPT_META_GROUPS (2..8,
+ * default 4) sets of codes (read by ReadSpatiallyCodedImage vp8l.h:191-223, SelectMetaHuffman :250-256); tiles are grouped by how busy
+ * their residuals are.  Both go with every other option and both dialects; neither is something the reference encoder produces. */
 /* VP8L_OPT_STANDARD: 0 (default) = the reference's private dialect (68-symbol code-length alphabet, 6-bit fields, codes of up to 64
  * bits, a zero chunk size: huffman_io.h:37-50,63-64, vp8l.h:461; libwebp cannot read it).  1 = the VP8L format of the WebP lossless
  * specification: 19-symbol code-length alphabet with 4-bit count and 3-bit lengths, codes limited to 15 bits, the real chunk size in
@@ -157,7 +167,8 @@ enum {
   VP8L_STAGE_CODELEN = 3,  /* 5 x 280 uint8 code lengths                                                 */
   VP8L_STAGE_INFO = 4,     /* uint32[4]: ncolors (0 = subtract-green path), bundling bits, xsize, M     */
   VP8L_STAGE_PRED_MODES = 5, /* uint32[3] tile bits, columns, rows, then one uint32 per tile (0 bytes: none) */
-  VP8L_STAGE_CROSS_ELEMS = 6 /* the same layout for the cross-colour elements                                */
+  VP8L_STAGE_CROSS_ELEMS = 6, /* the same layout for the cross-colour elements                                */
+  VP8L_STAGE_META_GROUPS = 7  /* the same layout: the Huffman group of every tile of the entropy image (0 bytes: none) */
 };
 long vp8l_encoder_fetch_stage(vp8l_encoder *enc, size_t image, int what, void *host_buf, size_t cap_bytes);
 

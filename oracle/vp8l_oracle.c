@@ -1312,7 +1312,7 @@ int ora_encode_ext(const uint32_t *argb, uint32_t w, uint32_t h, const ora_ext_p
       if (!meta || !mpix) { free(meta); free(mpix); free(img); free(bw.buf); return ORA_NOMEM; }
       uint32_t maxg = 0;
       for (uint32_t i = 0; i < mxs * mys; i++) {
-        meta[i] = (i % mxs + 2 * (i / mxs)) % ngroups;
+        meta[i] = prm->meta_image ? prm->meta_image[i] : (i % mxs + 2 * (i / mxs)) % ngroups;
         if (meta[i] > maxg) maxg = meta[i];
         mpix[i] = 0xff000000u | (meta[i] << 8);
       }

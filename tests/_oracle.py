@@ -38,7 +38,7 @@ class ExtParams(C.Structure):
         ("use_subtract_green", C.c_int), ("predictor_bits", C.c_int),
         ("predictor_modes", C.c_void_p), ("color_bits", C.c_int), ("color_elems", C.c_void_p),
         ("use_palette", C.c_int), ("cache_bits", C.c_int), ("meta_bits", C.c_int),
-        ("meta_groups", C.c_int), ("transform_order", C.c_int),
+        ("meta_groups", C.c_int), ("transform_order", C.c_int), ("meta_image", C.c_void_p),
     ]
 
 
@@ -183,7 +183,7 @@ def encode_ext(argb, w, h, **kw):
     keep = []
     prm = ExtParams()
     for k, v in kw.items():
-        if k in ("predictor_modes", "color_elems") and v is not None:
+        if k in ("predictor_modes", "color_elems", "meta_image") and v is not None:
             arr = np.ascontiguousarray(v, dtype=np.uint32)
             keep.append(arr)
             setattr(prm, k, arr.ctypes.data)

@@ -28,7 +28,7 @@ STATUS_NAMES = {
     -5: "InvalidVP8L", -6: "InvalidHuffman", -7: "NoDevice", -8: "MemoryAllocationException", -9: "HipError",
     -10: "BadArgument", -11: "Workspace",
 }
-STAGE_RESIDUAL, STAGE_MATCH, STAGE_HISTO, STAGE_CODELEN, STAGE_INFO, STAGE_PRED_MODES, STAGE_CROSS_ELEMS = range(7)
+STAGE_RESIDUAL, STAGE_MATCH, STAGE_HISTO, STAGE_CODELEN, STAGE_INFO, STAGE_PRED_MODES, STAGE_CROSS_ELEMS, STAGE_META_GROUPS = range(8)
 DEC_OPT_THREADS_PER_STREAM = 1
 DEC_OPT_WHOLE_DEVICE = 2
 DEC_OPT_SCOUT_FORM = 3
@@ -135,7 +135,7 @@ def riff_container(stream):
     return b"RIFF" + (8 + len(stream) + pad).to_bytes(4, "little") + b"WEBPVP8L" + stream + b"\0" * pad
 
 
-def encode(argb, width, height, predictor_bits=0, cross_color_bits=0, standard=False):
+def encode(argb, width, height, predictor_bits=0, cross_color_bits=0, standard=False, cache_bits=0, meta_bits=0):
     """VP8_LOSSLESS_ENCODER(argb, width, height).get_bit_writer() -> stream bytes (vp8l.h:585-615).
     predictor_bits 2..9 adds the predictor transform (not the reference encoder's bytes any more)."""
     a = None if argb is None else np.ascontiguousarray(argb, dtype=np.uint32)
@@ -144,7 +144,7 @@ def encode(argb, width, height, predictor_bits=0, cross_color_bits=0, standard=F
         raise Vp8lError(-1, "vp8l_encode (array holds %d pixels, %d x %d needs %d)" % (a.size, width, height, int(width) * int(height)))
     out = C.c_void_p()
     n = C.c_size_t()
-    rc = lib().vp8l_encode(a.ctypes.data if a is not None and a.size else None, width, height, C.byref(out), C.byref(n), int(predictor_bits) | (int(cross_color_bits) << 4) | (0x100 if standard else 0))
+    rc = lib().vp8l_encode(a.ctypes.data if a is not None and a.size else None, width, height, C.byref(out), C.byref(n), int(predictor_bits) | (int(cross_color_bits) << 4) | (0x100 if standard else 0) | (int(cache_bits) << 12) | (int(meta_bits) << 16))
     if rc != OK:
         raise Vp8lError(rc, "vp8l_encode")
     data = C.string_at(out.value, n.value)
@@ -278,7 +278,7 @@ class Encoder:
             raise Vp8lError(int(rc), "vp8l_encoder_fetch_stage")
         if what == STAGE_INFO:
             return dict(ncolors=int(info[0]), bits=int(info[1]), xsize=int(info[2]), M=int(info[3]))
-        if what in (STAGE_PRED_MODES, STAGE_CROSS_ELEMS):
+        if what in (STAGE_PRED_MODES, STAGE_CROSS_ELEMS, STAGE_META_GROUPS):
             buf = np.zeros(3 + 1024, dtype=np.uint32)
             rc = lib().vp8l_encoder_fetch_stage(self._h, image, what, buf.ctypes.data, buf.nbytes)
             if rc < 0:
@@ -286,7 +286,7 @@ class Encoder:
             if rc == 0:
                 return None
             tiles = buf[3:3 + int(buf[1]) * int(buf[2])].copy()
-            return dict(bits=int(buf[0]), tx=int(buf[1]), ty=int(buf[2]), modes=tiles, elems=tiles)
+            return dict(bits=int(buf[0]), tx=int(buf[1]), ty=int(buf[2]), modes=tiles, elems=tiles, groups=tiles)
         if what in (STAGE_RESIDUAL, STAGE_MATCH):
             buf = np.zeros(int(info[3]), dtype=np.uint32)
         elif what == STAGE_HISTO:
@@ -322,6 +322,20 @@ class Encoder:
     def set_standard(self, on):
         """False (default): the reference's dialect.  True: the standard VP8L format (what libwebp reads)."""
         rc = lib().vp8l_encoder_set_option(self._h, 4, 1 if on else 0)
+        if rc != OK:
+            raise Vp8lError(rc, "vp8l_encoder_set_option")
+
+    def set_cache_bits(self, bits):
+        """0 (default): no colour cache.  1..11: a colour cache of 2**bits entries."""
+        rc = lib().vp8l_encoder_set_option(self._h, 5, int(bits))
+        if rc != OK:
+            raise Vp8lError(rc, "vp8l_encoder_set_option")
+
+    def set_meta(self, bits, groups=4):
+        """bits 0 (default): one Huffman group.  2..9: an entropy image with tiles of 2**bits pixels and `groups` (2..8) groups."""
+        rc = lib().vp8l_encoder_set_option(self._h, 6, int(bits))
+        if rc == OK and bits:
+            rc = lib().vp8l_encoder_set_option(self._h, 7, int(groups))
         if rc != OK:
             raise Vp8lError(rc, "vp8l_encoder_set_option")
 

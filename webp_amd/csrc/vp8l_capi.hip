@@ -167,7 +167,7 @@ int get_pipeline(bool encoder, int device, int pred_bits, Pipeline **out) {
   HostContexts &c = contexts();
   std::lock_guard<std::mutex> lock(c.mu);
   std::map<int, Pipeline *> &m = encoder ? c.enc : c.dec;
-  const int key = encoder ? dev * 1024 + pred_bits : dev;  // pred_bits: predictor bits | cross-colour bits << 4 | standard dialect << 8
+  const int key = encoder ? dev * (1 << 20) + pred_bits : dev;  // pred_bits: predictor bits | cross-colour bits << 4 | standard dialect << 8 | cache bits << 12 | entropy-image bits << 16
   auto it = m.find(key);
   if (it == m.end()) {
     Pipeline *p = new (std::nothrow) Pipeline;
@@ -187,7 +187,9 @@ int lane_ready(Pipeline *p, Lane &l, bool encoder, int pred_bits) {
     if (rc != VP8L_OK) return rc;
     if (vp8l_encoder_set_option(l.enc, VP8L_OPT_PREDICTOR_BITS, pred_bits & 15) != VP8L_OK ||
         vp8l_encoder_set_option(l.enc, VP8L_OPT_CROSS_COLOR_BITS, (pred_bits >> 4) & 15) != VP8L_OK ||
-        vp8l_encoder_set_option(l.enc, VP8L_OPT_STANDARD, (pred_bits >> 8) & 1) != VP8L_OK)
+        vp8l_encoder_set_option(l.enc, VP8L_OPT_STANDARD, (pred_bits >> 8) & 1) != VP8L_OK ||
+        vp8l_encoder_set_option(l.enc, VP8L_OPT_CACHE_BITS, (pred_bits >> 12) & 15) != VP8L_OK ||
+        vp8l_encoder_set_option(l.enc, VP8L_OPT_META_BITS, (pred_bits >> 16) & 15) != VP8L_OK)
       return VP8L_ERR_BAD_ARGUMENT;
   }
   if (!encoder && !l.dec) {
@@ -367,14 +369,14 @@ extern "C" int vp8l_encode_batch(int device, size_t n, const uint32_t *const *ar
 
 extern "C" int vp8l_encode(const uint32_t *argb, uint32_t width, uint32_t height, uint8_t **out, size_t *out_len, uint32_t flags) {
   const int pred_bits = (int)(flags & VP8L_FLAG_PREDICTOR_BITS_MASK), cross_bits = (int)((flags & VP8L_FLAG_CROSS_COLOR_BITS_MASK) >> 4);
-  if (!out || !out_len || (flags & ~(uint32_t)(VP8L_FLAG_PREDICTOR_BITS_MASK | VP8L_FLAG_CROSS_COLOR_BITS_MASK | VP8L_FLAG_STANDARD)) || pred_bits == 1 || pred_bits > 9 ||
-      cross_bits == 1 || cross_bits > 9)
+  if (!out || !out_len || (flags & ~(uint32_t)(VP8L_FLAG_PREDICTOR_BITS_MASK | VP8L_FLAG_CROSS_COLOR_BITS_MASK | VP8L_FLAG_STANDARD | VP8L_FLAG_CACHE_BITS_MASK | VP8L_FLAG_META_BITS_MASK)) || pred_bits == 1 || pred_bits > 9 ||
+      cross_bits == 1 || cross_bits > 9 || ((flags >> 12) & 15) > 11 || ((flags >> 16) & 15) == 1 || ((flags >> 16) & 15) > 9)
     return VP8L_ERR_BAD_ARGUMENT;
   // argument checks of the reference constructor, in its order (vp8l.h:587-590)
   if (!argb || width == 0 || height == 0) return VP8L_ERR_INVALID_ARGB;
   if (width > kMaxDim || height > kMaxDim) return VP8L_ERR_TOO_BIG_ARGB;
   int status = VP8L_OK;
-  const int rc = guarded([&] { return encode_batch_with(-1, pred_bits | (cross_bits << 4) | ((flags & VP8L_FLAG_STANDARD) ? 256 : 0), 1, &argb, &width, &height, out, out_len, &status); });
+  const int rc = guarded([&] { return encode_batch_with(-1, pred_bits | (cross_bits << 4) | ((flags & VP8L_FLAG_STANDARD) ? 256 : 0) | (int)(flags & (VP8L_FLAG_CACHE_BITS_MASK | VP8L_FLAG_META_BITS_MASK)), 1, &argb, &width, &height, out, out_len, &status); });
   return rc != VP8L_OK ? rc : status;
 }
 

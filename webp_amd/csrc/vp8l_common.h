@@ -31,6 +31,7 @@ constexpr uint32_t kMaxLen = 128;      // LZ77_MAX_LENGTH
 constexpr uint32_t kMaxDim = 16384;    // MAX_ARGB_IMAGE_SIZE
 constexpr uint32_t kMaxCacheBits = 11; // MAX_COLOR_CACHE_BITS
 constexpr uint32_t kMaxPalette = 256;  // PALLETE_MAX_COLORS
+constexpr int kExtGreenMax = kAlphabetGreen + (1 << 11);  // the green alphabet with the largest colour cache (MAX_COLOR_CACHE_BITS)
 constexpr uint32_t kSmallMax = 1024;   // largest sub-image the header coder takes (a palette, or predictor modes of <= 1024 tiles)
 
 VP8L_HD int alphabet_size(int code) { return code == kGreen ? kAlphabetGreen : code == kDist ? kAlphabetDist : 256; }
@@ -52,6 +53,8 @@ VP8L_HD int cl_order(int i) {
 //   first 32 bits of the stream     zero (never patched)              the number of bytes that follow them (RIFF chunk size)
 //   predictor, last column          top-right := left (transform.h:137)   top-right := first pixel of the current row
 //   plane code giving a distance < 1   wraps (unsigned arithmetic)    distance 1
+//   tile grids after colour indexing   over the image's width            over the bundled width (entropy image; predictor and
+//   with bundled pixels                (vp8l.h:117-126,195-196)          cross-colour tiles)
 // A stream says which one it is: the reference never writes anything but zero into the first 32 bits, a standard
 // stream's chunk size is never zero.
 struct Dialect {

@@ -530,7 +530,8 @@ VP8L_HD uint32_t dec_step(DecState &st, const DecAccel &acc = DecAccel()) {
         st.meta_bits = 0; st.meta_xsize = 0;
         if (br.get(1)) {
           const uint32_t mb = br.get(3) + 2;
-          const uint32_t mx = (uint32_t)div_round_up(st.w, mb), my = (uint32_t)div_round_up(st.h, mb);
+          // the reference sizes the entropy image by the image's width (vp8l.h:195-196), the standard by the coded (bundled) width
+          const uint32_t mx = (uint32_t)div_round_up(st.standard && st.cix ? st.cix : st.w, mb), my = (uint32_t)div_round_up(st.h, mb);
           uint64_t off;
           if (!aux_alloc(st, (uint64_t)mx * my, off)) VP8L_FAIL(kErrWorkspace);
           st.meta_bits = mb;  // the sub-image reader below runs with one group and ignores it

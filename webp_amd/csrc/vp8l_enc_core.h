@@ -35,13 +35,16 @@ struct BitSink {
   VP8L_HD void flush() { words[nwords] = (uint32_t)acc; }
 };
 
-struct HuffScratch {
-  uint32_t wt[2 * kCodeStride];
-  uint16_t parent[2 * kCodeStride];
-  uint16_t ord[kCodeStride];
-  uint16_t stack[kCodeStride];
-  uint16_t depth[2 * kCodeStride];
+template <int N>
+struct HuffScratchT {  // for alphabets of up to N symbols
+  uint32_t wt[2 * N];
+  uint16_t parent[2 * N];
+  uint16_t ord[N];
+  uint16_t stack[N];
+  uint16_t depth[2 * N];
 };
+using HuffScratch = HuffScratchT<kCodeStride>;
+using HuffScratchBig = HuffScratchT<kExtGreenMax>;
 
 VP8L_HD uint32_t bit_reverse(uint32_t v, int len) {
   v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
@@ -65,7 +68,8 @@ VP8L_HD uint32_t bit_reverse(uint32_t v, int len) {
 // Returns the number of used symbols, or -3 (TooBigCodeLength, huffman_coding.h:410-413).
 // n <= kCodeStride.  presorted_used >= 0: the caller has already filled s.wt[0..used) with the used
 // symbols' weights in symbol order and s.ord with the leaf ids sorted by (weight, id).
-VP8L_HD int huffman_lengths(const uint32_t *histo, int n, int max_len, uint8_t *lengths, HuffScratch &s, int presorted_used = -1) {
+template <class Scratch>
+VP8L_HD int huffman_lengths(const uint32_t *histo, int n, int max_len, uint8_t *lengths, Scratch &s, int presorted_used = -1) {
   int nn = 0;
   if (presorted_used < 0) {
     for (int i = 0; i < n; i++)
@@ -124,7 +128,8 @@ VP8L_HD int huffman_lengths(const uint32_t *histo, int n, int max_len, uint8_t *
 // dialect allows 64); any complete prefix code within the limit is a valid stream there, so the usual remedy is used: counts
 // below a floor are raised to the floor and the code is built again, the floor doubling until the longest code fits.  The
 // floor starts where a code of `limit` bits becomes possible at all (total / 2^limit).  `histo` is changed in place.
-VP8L_HD int huffman_lengths_limited(uint32_t *histo, int n, int limit, uint8_t *lengths, HuffScratch &s, int presorted_used = -1) {
+template <class Scratch>
+VP8L_HD int huffman_lengths_limited(uint32_t *histo, int n, int limit, uint8_t *lengths, Scratch &s, int presorted_used = -1) {
   int used = huffman_lengths(histo, n, limit, lengths, s, presorted_used);
   if (used != -3) return used;
   uint64_t total = 0;
@@ -156,14 +161,17 @@ VP8L_HD void canonical_reversed_codes(const uint8_t *lengths, int n, uint32_t *c
   for (int i = 0; i < n; i++) codes[i] = lengths[i] ? bit_reverse(next[lengths[i]]++, lengths[i]) : 0;
 }
 
-struct DescScratch {
-  HuffScratch huff;
-  uint8_t rle_sym[kCodeStride + 8];
-  uint8_t rle_extra[kCodeStride + 8];
+template <int N>
+struct DescScratchT {  // for code descriptions of alphabets of up to N symbols
+  HuffScratch huff;  // the code-length code has at most 68 symbols
+  uint8_t rle_sym[N + 8];
+  uint8_t rle_extra[N + 8];
   uint32_t cl_histo[kNumClSyms];
   uint32_t cl_code[kNumClSyms];
   uint8_t cl_len[kNumClSyms];
 };
+using DescScratch = DescScratchT<kCodeStride>;
+using DescScratchBig = DescScratchT<kExtGreenMax>;
 
 // Run-length form of a code-length array (huffman_io.h:226-326).
 VP8L_HD int rle_code_lengths(const uint8_t *lengths, int n, uint8_t *sym, uint8_t *extra, const Dialect &dl = dialect_of(false)) {
@@ -193,7 +201,8 @@ VP8L_HD int rle_code_lengths(const uint8_t *lengths, int n, uint8_t *sym, uint8_
 
 // One code description (huffman_io.h:331-410).  Returns 0 or -3.  standard: the same description in the standard
 // dialect's code-length alphabet and field widths.
-VP8L_HD int write_code_desc(BitSink &bw, const uint8_t *lengths, int n, DescScratch &s, bool standard = false) {
+template <class Desc>
+VP8L_HD int write_code_desc(BitSink &bw, const uint8_t *lengths, int n, Desc &s, bool standard = false) {
   const Dialect dl = dialect_of(standard);
   int count = 0;
   uint32_t first[2] = {0, 0};

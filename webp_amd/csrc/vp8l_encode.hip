@@ -103,18 +103,32 @@ __global__ __launch_bounds__(256) void k_palette_scan(const EncImage *__restrict
 
 __global__ __launch_bounds__(256) void k_palette_finalize(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
                                                           const unsigned long long *__restrict__ gsets, uint32_t fuse, uint32_t pred_bits,
-                                                          uint32_t cross_bits) {
+                                                          uint32_t cross_bits, uint32_t meta_bits) {
   __shared__ uint32_t list[kSetSlots];
   __shared__ uint32_t s_k;
   const uint32_t img = blockIdx.x, tid = threadIdx.x;
   const EncImage im = imgs[img];
   EncState &s = st[img];
-  if (tid == 0) s_k = 0;
+  if (tid == 0) {
+    s_k = 0;
+    s.ngroups = 1;
+  }
+  // the entropy image's tiles: over the image's width and height in the reference's dialect (vp8l.h:195-196), over the coded
+  // (bundled) width in the standard one; the tile size grows until the header coder takes the image
+  auto meta_grid = [&](uint32_t grid_w) {
+    if (!meta_bits) return;
+    uint32_t b = meta_bits & 15u;
+    while (b < 9 && ((grid_w + (1u << b) - 1) >> b) * ((im.h + (1u << b) - 1) >> b) > kSmallMax) b++;
+    s.meta_bits = b;
+    s.meta_tx = (grid_w + (1u << b) - 1) >> b;
+    s.meta_ty = (im.h + (1u << b) - 1) >> b;
+  };
   __syncthreads();
   const bool none = s.pal_overflow || s.pal_count > kMaxPalette || s.pal_count == 0;
   if (none) {
     if (tid == 0) {
       s.ncolors = 0; s.bits = 0; s.xsize = im.w; s.M = im.w * im.h; s.xinv = dist_inverse(im.w);
+      meta_grid(im.w);
       // the candidate-list kernel reads 16 bytes at a time straight from the caller's pixels
       s.fused = fuse && (reinterpret_cast<uintptr_t>(im.argb) & 15) == 0;
       if (pred_bits) {  // the smallest tile size >= the requested one whose mode image fits the header coder
@@ -154,6 +168,7 @@ __global__ __launch_bounds__(256) void k_palette_finalize(const EncImage *__rest
     s.xsize = (im.w + (1u << bits) - 1) >> bits;
     s.M = s.xsize * im.h;
     s.xinv = dist_inverse(s.xsize);
+    meta_grid((meta_bits & 16u) ? s.xsize : im.w);  // bit 4: the standard dialect
   }
 }
 
@@ -1055,7 +1070,8 @@ struct HeaderShared {
 
 // The used symbols' weights in symbol order and their ids sorted by (weight, id), by the whole wave
 // (what huffman_lengths otherwise does with a serial insertion sort).  Returns the number of used symbols.
-__device__ __forceinline__ int wave_prepare_leaves(const uint32_t *h, int n, HuffScratch &hs, uint32_t lane) {
+template <class Scratch>
+__device__ __forceinline__ int wave_prepare_leaves(const uint32_t *h, int n, Scratch &hs, uint32_t lane) {
   uint32_t count = 0;
   for (int base = 0; base < n; base += 64) {
     const int i = base + (int)lane;
@@ -1107,7 +1123,7 @@ __device__ __forceinline__ void build_codes_4waves(uint32_t *histo5, CodeTables 
 __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
                                                         const uint32_t *__restrict__ histo, CodeTables *__restrict__ tables,
                                                         const uint32_t *__restrict__ modes, const uint32_t *__restrict__ elems,
-                                                        uint8_t *__restrict__ out, uint32_t standard) {
+                                                        uint8_t *__restrict__ out, uint32_t standard, ExtArgs ext) {
   __shared__ HeaderShared sh;
   __shared__ BitSink bw;
   __shared__ int s_rc;
@@ -1128,14 +1144,26 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
   // modes as pred_tx x pred_ty and then the cross-colour elements as cross_tx x cross_ty (read by ReadTransform
   // vp8l.h:111-121), in the order the transforms were applied.
   const uint32_t pred_bits = ncolors ? 0u : st[img].pred_bits, cross_bits = ncolors ? 0u : st[img].cross_bits;
-  for (int which = 0; which < 2; which++) {
-    const bool palette = which == 0 && ncolors, pred = which == 0 && pred_bits, cross = which == 1 && cross_bits;
-    if (!palette && !pred && !cross) continue;
-    const int np = palette ? (int)ncolors : pred ? (int)(st[img].pred_tx * st[img].pred_ty) : (int)(st[img].cross_tx * st[img].cross_ty);
-    const uint32_t sub_xsize = palette ? ncolors : pred ? st[img].pred_tx : st[img].cross_tx;
+  // which = 2: the entropy image (Huffman group of every tile), behind the transforms and the colour-cache bits
+  // (ReadSpatiallyCodedImage vp8l.h:180-215); only the coder with several groups writes one.
+  const uint32_t ngroups = ext.on ? st[img].ngroups : 1u;
+  for (int which = 0; which < 3; which++) {
+    const bool palette = which == 0 && ncolors, pred = which == 0 && pred_bits, cross = which == 1 && cross_bits, meta = which == 2 && ngroups > 1;
+    if (which == 2 && ext.on && tid == 0 && s_rc == 0) {
+      bw.put(0, 1);  // no more transforms
+      if (ext.cache_bits) { bw.put(1, 1); bw.put(ext.cache_bits, 4); } else bw.put(0, 1);   // vp8l.h:230-241
+      if (meta) { bw.put(1, 1); bw.put(st[img].meta_bits - 2, 3); } else bw.put(0, 1);      // vp8l.h:191-193
+    }
+    if (!palette && !pred && !cross && !meta) continue;
+    const int np = palette ? (int)ncolors : pred ? (int)(st[img].pred_tx * st[img].pred_ty) : cross ? (int)(st[img].cross_tx * st[img].cross_ty)
+                                                                                                   : (int)(st[img].meta_tx * st[img].meta_ty);
+    const uint32_t sub_xsize = palette ? ncolors : pred ? st[img].pred_tx : cross ? st[img].cross_tx : st[img].meta_tx;
     uint32_t *d = sh.sub.delta;
     if (palette) {
       if (tid < ncolors) d[tid] = tid ? px_sub(sh.palette[tid], sh.palette[tid - 1]) : sh.palette[0];
+    } else if (meta) {
+      const uint32_t *gi = ext.metaimg + (size_t)img * kSmallMax;
+      for (int i = (int)tid; i < np; i += 256) d[i] = 0xff000000u | (gi[i] << 8);  // the group index sits in the red and green bytes (vp8l.h:205-214)
     } else {
       const uint32_t *tiles = (pred ? modes : elems) + (size_t)img * kSmallMax;
       for (int i = (int)tid; i < np; i += 256) d[i] = tiles[i];
@@ -1171,6 +1199,25 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
       s_rc = rc;
     }
     __syncthreads();
+  }
+  if (ext.on) {
+    // the groups' codes were built and described by k_ext_codes: their descriptions follow one another (vp8l.h:217-222)
+    if (tid == 0) {
+      int rc = s_rc;
+      const size_t grp0 = (size_t)img * kExtMaxGroups;
+      for (uint32_t gk = 0; gk < ngroups * kNumCodes && rc == 0; gk++) {
+        rc = ext.rc[grp0 * kNumCodes + gk];
+        if (rc != 0) break;
+        const uint32_t *w = ext.desc + (grp0 * kNumCodes + gk) * kExtDescWords;
+        uint32_t left = ext.descbits[grp0 * kNumCodes + gk];
+        for (; left >= 32; left -= 32) bw.put(*w++, 32);
+        if (left) bw.put(*w, left);
+      }
+      bw.flush();
+      st[img].hdr_bits = (uint32_t)bw.bits();
+      st[img].status = rc;
+    }
+    return;
   }
   build_codes_4waves(sh.histo, sh.tables, sh.rc, hs, wave, lane, standard != 0);
   if (tid == 0) {
@@ -1485,6 +1532,10 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
   }
 }
 
+}  // namespace vp8l
+#include "vp8l_encode_ext.h"
+namespace vp8l {
+
 // =============================================================================================
 // Synthetic images on the device: x(k) = k-th state of the 32-bit LCG reached by jumping ahead.
 // =============================================================================================
@@ -1555,6 +1606,10 @@ struct vp8l_encoder {
   bool last_pred = false;
   bool last_cross = false;
   int cross_bits = 0;  // 0 = no cross-colour transform, else requested tile bits 2..9
+  int cache_bits = 0;   // 0 = no colour cache, else 1..11 (vp8l.h:230-241)
+  int meta_bits = 0;    // 0 = one Huffman group, else the requested tile bits 2..9 of the entropy image
+  int meta_groups = 4;  // Huffman groups when meta_bits is set (2..kExtMaxGroups)
+  DeviceBuffer x_hit, x_meta, x_feat, x_histo, x_tab, x_codes, x_desc, x_descbits, x_rc, x_rows;  // the extended coder's workspace
   bool standard = false;  // write the standard dialect (what libwebp reads) instead of the reference's
   int pred_bits = 0;   // 0 = no predictor transform (the reference encoder's output), else requested tile bits 2..9
   // last batch
@@ -1588,7 +1643,8 @@ struct EncBuffers {
 // Clears what must start at zero and launches every kernel of the encode path for nl images that occupy sb_total
 // superblocks; imgs and sbf are already on their way on the same stream.  ev: ten events for stage times, or null.
 static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl, uint32_t sb_total, uint32_t pred, uint32_t cross,
-                                 int match_mode, uint8_t *d_out, hipEvent_t *ev, uint32_t standard = 0) {
+                                 int match_mode, uint8_t *d_out, hipEvent_t *ev, uint32_t standard = 0, const ExtArgs *extp = nullptr,
+                                 uint32_t meta_bits = 0) {
   bool h = true;
   h = h && hip_ok(hipMemsetAsync(B.st, 0, nl * sizeof(EncState), s), "clear state");
   h = h && hip_ok(hipMemsetAsync(B.gsets, 0xff, (size_t)nl * kSetSlots * sizeof(unsigned long long), s), "clear sets");
@@ -1599,7 +1655,7 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   const uint32_t gsb = sb_total, gunits = sb_total * kUnitsPerSuper;
   mark(0);
   hipLaunchKernelGGL(k_palette_scan, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.gsets);
-  hipLaunchKernelGGL(k_palette_finalize, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.gsets, (match_mode == 0 && !pred && !cross) ? 1u : 0u, pred, cross);
+  hipLaunchKernelGGL(k_palette_finalize, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.gsets, (match_mode == 0 && !pred && !cross) ? 1u : 0u, pred, cross, meta_bits | (meta_bits && standard ? 16u : 0u));
   mark(1);
   hipLaunchKernelGGL(k_transform, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix_t);
   if (pred) {
@@ -1623,14 +1679,43 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   hipLaunchKernelGGL(k_parse_chain, dim3(nl), dim3(256), 0, s, B.st, B.sbf, B.sx, B.entry);
   hipLaunchKernelGGL(k_parse_mark, dim3(gsb), dim3(128), 0, s, B.imgs, B.st, B.sbf, nl, B.adv8, B.entry, B.flags);
   mark(4);
+  ExtArgs ext;
+  memset(&ext, 0, sizeof(ext));
+  if (extp) ext = *extp;
+  ext.standard = standard;
+  if (ext.on) {
+    // the coder with a colour cache and / or several Huffman groups (vp8l_encode_ext.h); stage times: "histogram" = everything up
+    // to the codes, the others as in the default coder
+    uint32_t *hitbits = const_cast<uint32_t *>(ext.hitbits);
+    if (ext.cache_bits) {
+      hipLaunchKernelGGL(k_cache_rows, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, ext);
+      hipLaunchKernelGGL(k_cache_scan, dim3(nl), dim3(256), 0, s, B.st, B.sbf, ext);
+      hipLaunchKernelGGL(k_cache_hits, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, hitbits, ext);
+    }
+    if (ext.groups > 1) {
+      hipLaunchKernelGGL(k_meta_feature, dim3(nl * kSmallMax), dim3(64), 0, s, B.imgs, B.st, B.pix, ext);
+      hipLaunchKernelGGL(k_meta_assign, dim3(nl), dim3(256), 0, s, B.st, ext);
+    }
+    if (!hip_ok(hipMemsetAsync(ext.histo, 0, (size_t)nl * kExtMaxGroups * kExtSyms * 4, s), "clear group histograms")) return VP8L_ERR_HIP;
+    hipLaunchKernelGGL(k_ext_histogram, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, ext);
+    hipLaunchKernelGGL(k_ext_codes, dim3(nl * kExtMaxGroups * kNumCodes), dim3(64), 0, s, B.st, ext);
+    mark(5);
+    hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.histo, B.tables, B.modes, B.elems, d_out, standard, ext);
+    mark(6);
+    hipLaunchKernelGGL(k_ext_bitcount, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.gbits, B.ubits, ext);
+    hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.sbf, B.ubits, B.uoff, d_out, standard);
+    mark(7);
+    hipLaunchKernelGGL(k_ext_emit, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.gbits, B.uoff, d_out, ext);
+  } else {
   hipLaunchKernelGGL(k_histogram, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.histo);
   mark(5);
-  hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.histo, B.tables, B.modes, B.elems, d_out, standard);
+  hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.histo, B.tables, B.modes, B.elems, d_out, standard, ext);
   mark(6);
   hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables, B.gbits, B.ubits);
   hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.sbf, B.ubits, B.uoff, d_out, standard);
   mark(7);
   hipLaunchKernelGGL(k_emit, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables, B.gbits, B.uoff, d_out);
+  }
   mark(8);
   if (!hip_ok(hipGetLastError(), "kernel launch")) return VP8L_ERR_HIP;
   return VP8L_OK;
@@ -1663,7 +1748,8 @@ extern "C" void vp8l_encoder_destroy(vp8l_encoder *e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (auto &ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   DeviceBuffer *bufs[] = {&e->d_imgs, &e->d_state, &e->d_sbfirst, &e->d_gsets, &e->d_pix, &e->d_match, &e->d_flags,
-                          &e->d_histo, &e->d_tables, &e->d_sx, &e->d_entry, &e->d_unit_bits, &e->d_unit_off, &e->d_dense, &e->d_group_bits, &e->d_adv, &e->d_pix2, &e->d_modes, &e->d_elems};
+                          &e->d_histo, &e->d_tables, &e->d_sx, &e->d_entry, &e->d_unit_bits, &e->d_unit_off, &e->d_dense, &e->d_group_bits, &e->d_adv, &e->d_pix2, &e->d_modes, &e->d_elems,
+                          &e->x_hit, &e->x_meta, &e->x_feat, &e->x_histo, &e->x_tab, &e->x_codes, &e->x_desc, &e->x_descbits, &e->x_rc, &e->x_rows};
   for (auto *b : bufs) b->release();
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -1759,7 +1845,31 @@ static int vp8l_encoder_encode_device_impl(vp8l_encoder *e, size_t n, const uint
   h = h && hip_ok(hipMemcpyAsync(B.imgs, e->imgs.data(), nl * sizeof(EncImage), hipMemcpyHostToDevice, s), "upload images");
   h = h && hip_ok(hipMemcpyAsync(B.sbf, e->sb_first.data(), (nl + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s), "upload table");
   if (!h) return VP8L_ERR_HIP;
-  rc_launch = launch_encode_kernels(s, B, nl, (uint32_t)sb_total, pred, cross, e->match_mode, d_out, e->ev, e->standard ? 1u : 0u);
+  ExtArgs ext;
+  memset(&ext, 0, sizeof(ext));
+  if (e->cache_bits || e->meta_bits) {
+    const size_t groups = (size_t)nl * kExtMaxGroups;
+    if (!e->x_hit.reserve(npos / 8 + 256) || !e->x_meta.reserve((size_t)nl * kSmallMax * 4) || !e->x_feat.reserve((size_t)nl * kSmallMax * 4) ||
+        !e->x_histo.reserve(groups * kExtSyms * 4) || !e->x_tab.reserve(groups * kExtTabStride * sizeof(uint2)) || !e->x_codes.reserve(groups * kExtSyms * 4) ||
+        !e->x_desc.reserve(groups * kNumCodes * kExtDescWords * 4) || !e->x_descbits.reserve(groups * kNumCodes * 4) || !e->x_rc.reserve(groups * kNumCodes * 4) ||
+        (e->cache_bits && !e->x_rows.reserve((sb_total << e->cache_bits) * 4)))
+      return VP8L_ERR_NO_MEMORY;
+    ext.on = 1;
+    ext.cache_bits = (uint32_t)e->cache_bits;
+    ext.groups = e->meta_bits ? (uint32_t)e->meta_groups : 1u;
+    ext.hitbits = e->x_hit.as<uint32_t>();
+    ext.metaimg = e->x_meta.as<uint32_t>();
+    ext.feature = e->x_feat.as<uint32_t>();
+    ext.histo = e->x_histo.as<uint32_t>();
+    ext.tab = e->x_tab.as<uint2>();
+    ext.codes = e->x_codes.as<uint32_t>();
+    ext.desc = e->x_desc.as<uint32_t>();
+    ext.descbits = e->x_descbits.as<uint32_t>();
+    ext.rc = e->x_rc.as<int32_t>();
+    ext.rows = e->x_rows.as<uint32_t>();
+  }
+  rc_launch = launch_encode_kernels(s, B, nl, (uint32_t)sb_total, pred, cross, e->match_mode, d_out, e->ev, e->standard ? 1u : 0u, &ext,
+                                    (uint32_t)e->meta_bits);
   if (rc_launch != VP8L_OK) return rc_launch;
   if (!hip_ok(hipMemcpyAsync(e->states.data(), st, nl * sizeof(EncState), hipMemcpyDeviceToHost, s), "download state")) return VP8L_ERR_HIP;
   if (!hip_ok(hipStreamSynchronize(s), "encode batch")) return VP8L_ERR_HIP;
@@ -1832,6 +1942,14 @@ extern "C" long vp8l_encoder_fetch_stage(vp8l_encoder *e, size_t image, int what
       memcpy(host_buf, info, 12);
       if (!hip_ok(hipMemcpy(static_cast<uint8_t *>(host_buf) + 12, e->d_elems.as<uint32_t>() + slot * kSmallMax, bytes - 12, hipMemcpyDeviceToHost), "fetch elements")) return VP8L_ERR_HIP;
       return (long)bytes;
+    case VP8L_STAGE_META_GROUPS:  // the same layout: the Huffman group of every tile of the entropy image
+      if (!e->meta_bits || st.meta_bits == 0) return 0;
+      info[0] = st.meta_bits; info[1] = st.meta_tx; info[2] = st.meta_ty;
+      bytes = 12 + (size_t)st.meta_tx * st.meta_ty * 4;
+      if (bytes > cap) return VP8L_ERR_BAD_ARGUMENT;
+      memcpy(host_buf, info, 12);
+      if (!hip_ok(hipMemcpy(static_cast<uint8_t *>(host_buf) + 12, e->x_meta.as<uint32_t>() + slot * kSmallMax, bytes - 12, hipMemcpyDeviceToHost), "fetch groups")) return VP8L_ERR_HIP;
+      return (long)bytes;
     case VP8L_STAGE_MATCH: src = e->d_match.as<uint32_t>() + im.pos0; bytes = (size_t)st.M * 4; break;
     case VP8L_STAGE_HISTO: src = e->d_histo.as<uint32_t>() + slot * kNumCodes * kCodeStride; bytes = kNumCodes * kCodeStride * 4; break;
     case VP8L_STAGE_CODELEN: src = e->d_tables.as<CodeTables>()[slot].len; bytes = kNumCodes * kCodeStride; break;
@@ -1864,6 +1982,9 @@ extern "C" int vp8l_encoder_set_option(vp8l_encoder *e, int option, int value) {
   if (option == VP8L_OPT_PREDICTOR_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->pred_bits = value; return VP8L_OK; }
   if (option == VP8L_OPT_CROSS_COLOR_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->cross_bits = value; return VP8L_OK; }
   if (option == VP8L_OPT_STANDARD && (value == 0 || value == 1)) { e->standard = value != 0; return VP8L_OK; }
+  if (option == VP8L_OPT_CACHE_BITS && value >= 0 && value <= (int)kMaxCacheBits) { e->cache_bits = value; return VP8L_OK; }
+  if (option == VP8L_OPT_META_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->meta_bits = value; return VP8L_OK; }
+  if (option == VP8L_OPT_META_GROUPS && value >= 2 && value <= (int)kExtMaxGroups) { e->meta_groups = value; return VP8L_OK; }
   return VP8L_ERR_BAD_ARGUMENT;
 }
 

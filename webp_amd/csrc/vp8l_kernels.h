@@ -40,13 +40,42 @@ struct EncState {          // device-written
   uint32_t pred_tx, pred_ty;
   uint32_t cross_bits;     // cross-colour transform: tile size 2^bits (0 = none), cross_tx x cross_ty tiles
   uint32_t cross_tx, cross_ty;
-  uint32_t pad_cross;
+  uint32_t ngroups;        // Huffman groups of the main image (1 unless an entropy image is written)
+  uint32_t meta_bits;      // entropy image: tile size 2^bits (0 = none), meta_tx x meta_ty tiles over the image's width and height
+  uint32_t meta_tx, meta_ty;
+  uint32_t pad_meta;
   uint32_t hdr_bits;       // bits in front of the first token
   int32_t status;
   uint64_t total_bits;
   uint32_t pal_count;      // distinct colours seen so far (palette detection)
   uint32_t pal_overflow;
   uint32_t palette[kMaxPalette];
+};
+
+// ---- the coder with a colour cache and several Huffman groups (vp8l_encode_ext.h) -------------------------
+constexpr uint32_t kExtGreen = (uint32_t)kExtGreenMax;  // 280 + 2048
+constexpr uint32_t kExtRed = kExtGreen, kExtBlue = kExtRed + 256, kExtAlpha = kExtBlue + 256, kExtDist = kExtAlpha + 256;
+constexpr uint32_t kExtSyms = kExtDist + kAlphabetDist;  // symbols of one group, the five codes one after the other
+constexpr uint32_t kExtZero = kExtSyms;                  // a (0, 0) entry behind them
+constexpr uint32_t kExtTabStride = kExtSyms + 2;
+constexpr uint32_t kExtMaxGroups = 8;
+constexpr uint32_t kExtDescWords = 4096;                 // room for one code description: 2328 items of at most 39 bits and the head
+
+struct ExtArgs {   // by value to the kernels
+  uint32_t on;            // 0: the default coder
+  uint32_t cache_bits;    // 0 = no colour cache
+  uint32_t groups;        // 1 = no entropy image, else the number of groups asked for (an image may end up with fewer)
+  uint32_t standard;
+  const uint32_t *hitbits;   // per position (bit array like the parse flags): the pixel is in the cache
+  uint32_t *metaimg;         // per image kSmallMax tiles: group of the tile
+  uint32_t *feature;         // per image kSmallMax tiles: rough bit cost per pixel, in 1/16
+  uint32_t *histo;           // per image kExtMaxGroups x kExtSyms counts
+  uint2 *tab;                // per image kExtMaxGroups x kExtTabStride (code, length); length 0 for codes that are not written
+  uint32_t *codes;           // per image kExtMaxGroups x kExtSyms: scratch for the codes
+  uint32_t *desc;            // per image kExtMaxGroups x 5 x kExtDescWords: the code descriptions, bit-packed
+  uint32_t *descbits;        // per image kExtMaxGroups x 5: their lengths in bits
+  int32_t *rc;               // per image kExtMaxGroups x 5: 0 or the failure of that code
+  uint32_t *rows;            // per superblock 2^cache_bits: last position + 1 of every key (k_cache_rows / k_cache_scan)
 };
 
 __device__ __forceinline__ uint32_t find_image(const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t sb) {
