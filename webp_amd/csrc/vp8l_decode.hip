@@ -9,6 +9,7 @@
 //                        as a skewed wavefront (row y trails row y-1 by two pixels).
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -490,17 +491,25 @@ __device__ __forceinline__ void wg_token(uint64_t w, const VP8L_LDS GroupTables 
   }
 }
 
-__device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, const VP8L_LDS GroupTables *g_, VP8L_LDS uint32_t *ring,
+// Several Huffman groups (vp8l.h:250-256): the group is that of the tile in which a token STARTS, so a round runs with the tables of
+// the group at the current pixel and takes only the tokens that start before the next tile with another group; when the group
+// changes, that group's tables are copied from HBM into the same LDS place (a few words per thread).
+__device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, VP8L_LDS GroupTables *g_, VP8L_LDS uint32_t *ring,
                                               VP8L_LDS uint32_t *win, VP8L_LDS WgShared *sh_, const DecImage &im, uint32_t tid) {
   VP8L_LDS DecState &st = *st_;
-  const VP8L_LDS GroupTables &g = *g_;
+  VP8L_LDS GroupTables &g = *g_;
   VP8L_LDS WgShared &sh = *sh_;
+  const bool multi = st.ngroups > 1;
+  const uint32_t *meta = st.meta;
+  const uint32_t mbits = st.meta_bits, mxs = st.meta_xsize, width = st.xsize, rows = st.ysize;
+  const GroupTables *all_groups = st.groups;   // HBM, when there are several
+  uint32_t gcur = 0xffffffffu;                 // the group whose tables are in LDS
   const uint32_t lane = tid & 63, wave = tid >> 6;
   constexpr uint32_t kMask = kWgRing - 1;
   uint64_t P = st.bytepos * 8 - st.cnt;  // position in the stream, in bits
   const uint32_t total = (uint32_t)st.total, xsize = st.xsize | (st.standard << 31);  // bit 31: the dialect, for the distance codes
   uint32_t *dst = st.dst;
-  wg_prepare_long(sh, g, tid);
+  if (!multi) wg_prepare_long(sh, g, tid);
   uint32_t fill = 0, flushed = 0;  // flushed: multiple of 64, everything before it is in HBM
   uint64_t win_bit0 = 0;
   bool have_window = false;
@@ -511,6 +520,38 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, const VP8L
     sh.jb[kWgSpan] = (uint16_t)kWgSpan;
   }
   while (fill < total) {
+    uint32_t span_px = 0xffffffffu;  // tokens that start this many pixels or more after `fill` wait for another round
+    if (multi) {
+      // the run of tiles from the current pixel on that share its group (up to eight tiles ahead, all looked up at once)
+      const uint32_t y = fill / width, x = fill - y * width;
+      const uint32_t tiles_x = (width + (1u << mbits) - 1) >> mbits;  // tiles that hold coded pixels (the entropy image may be wider)
+      uint32_t gi[9], px_end[9];
+      uint32_t tx = x >> mbits, ty = y, acc_px = 0, cx = x;
+#pragma unroll
+      for (uint32_t k = 0; k < 9; k++) {
+        gi[k] = meta[((ty < rows ? ty : rows - 1) >> mbits) * mxs + tx];  // past the last row: only looked at, never used
+        const uint32_t tile_end = ((tx + 1) << mbits) < width ? ((tx + 1) << mbits) : width;
+        acc_px += tile_end - cx;
+        px_end[k] = acc_px;
+        cx = tile_end;
+        tx++;
+        if (tx >= tiles_x) { tx = 0; cx = 0; ty++; }
+      }
+      span_px = px_end[0];
+#pragma unroll
+      for (uint32_t k = 1; k < 9; k++) {
+        if (gi[k] != gi[0]) break;
+        span_px = px_end[k];
+      }
+      if (gi[0] != gcur) {
+        __syncthreads();  // nobody still reads the tables of the group before
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&all_groups[gi[0]]);
+        for (uint32_t i = tid; i < sizeof(GroupTables) / 4; i += kWgThreads) reinterpret_cast<VP8L_LDS uint32_t *>(&g)[i] = src[i];
+        __syncthreads();
+        wg_prepare_long(sh, g, tid);
+        gcur = gi[0];
+      }
+    }
     if (!have_window || P < win_bit0 || P + kWgSpan + 128 > win_bit0 + kWgWindow * 8) {
       __syncthreads();
       const uint64_t lo = (P >> 3) & ~3ull;
@@ -587,12 +628,11 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, const VP8L
         sh.end_px = ex;
       } else {
         if (s1[0] == kWgSpan) { sh.end_off = tid + hop; sh.end_px = ex + cnt; }
-        if (ex + cnt > room) {
-          if (ex <= room) {  // the first token that does not fit: the next round starts with it
-            sh.defer_off = tid;
-            sh.defer_px = ex;
-            if (room == left && ex < room) sh.status = kErrInvalidVp8l;  // a reference that runs past the end of the image
-          }
+        if (ex + cnt > room || ex >= span_px) {
+          // the first token that does not fit, or that starts in a tile with other codes: the next round starts with it
+          // (tokens lie in stream order, so the smallest offset is the first; offset and pixels in one word)
+          __hip_atomic_fetch_min(&sh.defer_off, (tid << 16) | (ex < 0xffffu ? ex : 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (ex + cnt > room && ex <= room && ex < span_px && room == left && ex < room) sh.status = kErrInvalidVp8l;  // a reference that runs past the end of the image
         } else if (!ref) {
           ring[pos & kMask] = val;
           sh.srcp[ex] = pos | kFinal;
@@ -638,7 +678,7 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, const VP8L
     status = sh.status;
     if (status != kOk) break;
     const bool deferred = sh.defer_off != 0xffffffffu;
-    const uint32_t adv = deferred ? sh.defer_off : sh.end_off, produced = deferred ? sh.defer_px : sh.end_px;
+    const uint32_t adv = deferred ? sh.defer_off >> 16 : sh.end_off, produced = deferred ? sh.defer_off & 0xffffu : sh.end_px;
     // Sources that are made by a reference of this round are replaced by that pixel's source until every pixel
     // points at a final one: chains of references (a run coded as copies of 1, 2, 4, 8 ... pixels) take
     // log2(chain length) steps instead of one copy after the other.  A source read while its owner replaces
@@ -1547,6 +1587,7 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
   acc.ring_mask = kWgRing - 1;
   acc.g0 = &g0;
   acc.driver_pixels = true;
+  acc.driver_multi = true;
   acc.on = true;
   if (tid == 0) {
     dec_init(st, im.data, im.len, im.out, im.aux, im.aux_cap, &g0, im.groups, im.group_cap, im.cache, &ros.scratch, im.sorted);
@@ -1560,7 +1601,7 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
     const uint32_t ev = s_ev;
     if (ev == kEvDone) break;
     if (ev == kEvPixels) {
-      if (im.par && st.dst == st.out && st.total >= kParMinPixels) {
+      if (im.par && st.dst == st.out && st.total >= kParMinPixels && st.ngroups == 1) {
         // the main image of a large stream: its pixels are decoded by the segment kernels that follow, from these tables
         ParImage *par = im.par;
         for (uint32_t i = tid; i < sizeof(GroupTables) / 4; i += kWgThreads)
@@ -1581,7 +1622,7 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
         __syncthreads();
         break;
       }
-      wg_decode_pixels((VP8L_LDS DecState *)&st, (const VP8L_LDS GroupTables *)&g0, (VP8L_LDS uint32_t *)ros.ring,
+      wg_decode_pixels((VP8L_LDS DecState *)&st, (VP8L_LDS GroupTables *)&g0, (VP8L_LDS uint32_t *)ros.ring,
                        (VP8L_LDS uint32_t *)win, (VP8L_LDS WgShared *)&sh, im, tid);
     } else if (ev == kEvRefill) {
       const uint64_t lo = st.bytepos;
@@ -2176,9 +2217,9 @@ static int vp8l_decoder_decode_device_impl(vp8l_decoder *d, size_t n, const uint
       parts.back().push_back(i);
       acc += len[i];
     }
-    for (auto it = parts.rbegin(); it != parts.rend(); ++it) todo.push_back({std::move(*it), 1, 4, true});  // popped from the back
+    for (auto it = parts.rbegin(); it != parts.rend(); ++it) todo.push_back({std::move(*it), 1, 8, true});  // popped from the back
   } else {
-    todo.push_back({pending, 0, 4, true});
+    todo.push_back({pending, 0, 8, true});
   }
   while (!todo.empty()) {
     Todo t = std::move(todo.back());
@@ -2205,13 +2246,17 @@ static int vp8l_decoder_decode_device_impl(vp8l_decoder *d, size_t n, const uint
       continue;
     }
     if (rc != VP8L_OK) return rc;
+    std::map<uint32_t, std::vector<uint32_t>> more_groups;
     Todo with_maps{{}, 2, t.group_cap, t.pred_bands}, one_workgroup{{}, 0, t.group_cap, t.pred_bands},
         one_block_predictor{{}, t.mode, t.group_cap, false};
     for (size_t k = 0; k < t.idx.size(); k++) {
       const DecResult &r = results[k];
       if (r.status == kErrWorkspace && r.need_groups > t.group_cap) {
-        // a pass sizes every image's tables by one count: an image that needs more gets a pass of its own with exactly its count
-        todo.push_back({std::vector<uint32_t>(1, t.idx[k]), t.mode, r.need_groups, t.pred_bands});
+        // a pass sizes every image's tables by one count: images that need more go on together with those whose need rounds up to the
+        // same power of two (so one stream with thousands of groups sizes only its own pass)
+        uint32_t cap = 8;
+        while (cap < r.need_groups) cap <<= 1;
+        more_groups[cap].push_back(t.idx[k]);
       } else if (r.status == kPredRetry) {
         one_block_predictor.idx.push_back(t.idx[k]);  // a band of the predictor inverse waited too long for the band above
       } else if (r.status == kParRetryMaps && t.mode == 1) {
@@ -2224,6 +2269,7 @@ static int vp8l_decoder_decode_device_impl(vp8l_decoder *d, size_t n, const uint
         if (t.mode == 1 && r.pad == 1) d->last_scouted++;
       }
     }
+    for (auto &mg : more_groups) todo.push_back({std::move(mg.second), t.mode, mg.first, t.pred_bands});
     for (Todo *n2 : {&with_maps, &one_workgroup, &one_block_predictor})
       if (!n2->idx.empty()) todo.push_back(std::move(*n2));
   }

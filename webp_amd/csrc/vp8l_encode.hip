@@ -12,13 +12,16 @@
 //                                         candidate lists give up on                  lz77.h:51-72
 //   k_parse_exits / k_parse_chain / k_parse_mark   the greedy parse (which positions start a token)
 //                                                                  lz77.h:33-92
-//   k_histogram                           the five symbol histograms          vp8l.h:516-535
+//                                         (k_parse_mark also counts the symbols: the five histograms, vp8l.h:516-535)
 //   k_entropy_header                      Huffman codes + everything in front of the tokens
 //                                                                  vp8l.h:460-467,536-540; huffman_io.h:331-410
 //   k_bitcount / k_scan / k_emit          token bits              vp8l.h:545-583, bit_writer.h:45-64
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <string>
@@ -616,7 +619,8 @@ static_assert(kSpTile == kLzTile, "one flag per tile");
 __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                      const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
                                                      uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
-                                                     uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
+                                                     uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile, uint32_t tune_per_value,
+                                                     uint32_t tune_budget, uint32_t tune_max_bucket) {
   __shared__ __attribute__((aligned(16))) uint32_t px[kSpSources + kMaxLen + 4];
   __shared__ uint16_t runlen[kSpSources + kMaxLen];  // pixels equal to this one from here on (within the window)
   // counts, then insert positions; after the scatter cursor[h] = end of bucket h.  16 bits each (at most kSpSources), two to
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   for (int k = 0; k < 8; k++) { sum += c[k]; mx = c[k] > mx ? c[k] : mx; }
   const uint32_t incl = wave_incl_scan_u32(sum, (int)lane);
   if (lane == 63) wsum[wave] = incl;
-  if (mx > kSpMaxBucket) s_abort = 1;
+  if (mx > tune_max_bucket) s_abort = 1;
   if (mx >= kSpHeavyBucket) s_heavy = 1;
   __syncthreads();
   if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
@@ -761,7 +765,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
     __syncthreads();
     uint32_t entries = 0;
     for (uint32_t k = 0; k < kSpWaves; k++) entries += wsum[k];
-    if (entries > kSpMaxPerValue * s_nonempty) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
+    if (entries > tune_per_value * s_nonempty) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
         if ((it ^ tag) >> kSpPosBits || s >= ip || s < wlo) continue;  // another value, or not one of the 1024 before p
         source_run(s);
       }
-      if (spent > kSpBudget) over = true;
+      if (spent > tune_budget) over = true;
       if (p == M - 1) key = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
     }
     out[k] = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_code_of(xsize, xinv, key & 2047u) << 19)) : 0u;
@@ -890,8 +894,8 @@ __global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs,
 constexpr uint32_t kRowPad = kBlockLen + 4;  // LDS row stride: spreads the 128 block rows over the banks
 
 // adv8[p] = max(1, len[p]) as written by the match kernels; positions at and past M read as 1
-__device__ __forceinline__ void load_advances(const uint8_t *__restrict__ adv8, uint32_t M, uint32_t p0, uint8_t *adv, uint32_t tid) {
-  for (uint32_t i = tid * 16; i < kSuper; i += 128 * 16) {
+__device__ __forceinline__ void load_advances(const uint8_t *__restrict__ adv8, uint32_t M, uint32_t p0, uint8_t *adv, uint32_t tid, uint32_t threads = 128) {
+  for (uint32_t i = tid * 16; i < kSuper; i += threads * 16) {
     uint4 v = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
     if (p0 + i + 15 < M) {
       v = *reinterpret_cast<const uint4 *>(adv8 + p0 + i);
@@ -950,85 +954,79 @@ __global__ __launch_bounds__(256) void k_parse_chain(const EncState *__restrict_
   }
 }
 
-__global__ __launch_bounds__(128) void k_parse_mark(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
-                                                    const uint32_t *__restrict__ sb_first, uint32_t n,
-                                                    const uint8_t *__restrict__ adv8, const uint8_t *__restrict__ entry,
-                                                    uint32_t *__restrict__ flags) {
-  __shared__ __attribute__((aligned(16))) uint8_t adv[kBlocksPerSuper * kRowPad];  // exits first, then the advances again
+// Marks the token starts of a superblock and, in the same kernel, counts their symbols (vp8l.h:516-535): the walks above are
+// chains of dependent LDS reads that leave the memory system idle, the histogram is loads and LDS atomics, so the workgroups of
+// one CU overlap the two.  The histogram takes over the LDS of the advances once the marks are made.
+constexpr uint32_t kHistCopies = 3;  // interleaved copies of every counter: equal symbols in one wave meet less often
+__device__ __forceinline__ void histo_add(uint32_t *h, uint32_t sym) {
+  // One count per active lane.  Lanes that all hold the same symbol (an opaque alpha channel, a flat colour plane) would
+  // serialise on one LDS address: then one lane adds the number of lanes.
+  const uint64_t active = __ballot(1);
+  const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym);
+  if (__ballot(sym == first) == active) {
+    if ((uint32_t)__builtin_ctzll(active) == (threadIdx.x & 63u)) atomicAdd(&h[first * kHistCopies], (uint32_t)__popcll(active));
+  } else {
+    atomicAdd(&h[sym * kHistCopies + (threadIdx.x % kHistCopies)], 1u);
+  }
+}
+
+constexpr uint32_t kMarkThreads = 256;
+__global__ __launch_bounds__(kMarkThreads) void k_parse_mark(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                             const uint32_t *__restrict__ sb_first, uint32_t n,
+                                                             const uint8_t *__restrict__ adv8, const uint8_t *__restrict__ entry,
+                                                             uint32_t *__restrict__ flags, const uint32_t *__restrict__ pix,
+                                                             const uint32_t *__restrict__ match, uint32_t *__restrict__ histo) {
+  constexpr uint32_t kAdvBytes = kBlocksPerSuper * kRowPad, kHistWords = kNumCodes * kCodeStride * kHistCopies;
+  static_assert(kHistWords * 4 <= kAdvBytes, "the histogram fits where the advances were");
+  __shared__ __attribute__((aligned(16))) uint8_t adv[kAdvBytes];  // exits first, then the advances again, then the histogram
   __shared__ uint8_t ent[kBlocksPerSuper];
+  __shared__ __attribute__((aligned(16))) uint32_t fl[kSuper / 32];  // token starts of the superblock
   const uint32_t sb = blockIdx.x, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   const uint32_t M = st[img].M;
   const uint32_t p0 = (sb - sb_first[img]) * kSuper;
   if (p0 >= M) return;
-  load_advances(adv8 + imgs[img].pos0, M, p0, adv, tid);
+  const uint64_t pos0 = imgs[img].pos0;
+  load_advances(adv8 + pos0, M, p0, adv, tid, kMarkThreads);
   __syncthreads();
-  block_exits_in_place(adv, tid);
+  if (tid < kBlocksPerSuper) block_exits_in_place(adv, tid);
   __syncthreads();
   if (tid == 0) {
     uint32_t e = entry[sb];
     for (uint32_t r = 0; r < kBlocksPerSuper; r++) { ent[r] = (uint8_t)e; e = adv[r * kRowPad + e]; }
   }
   __syncthreads();
-  load_advances(adv8 + imgs[img].pos0, M, p0, adv, tid);  // the same 16 KiB again, from cache
+  load_advances(adv8 + pos0, M, p0, adv, tid, kMarkThreads);  // the same 16 KiB again, from cache
   __syncthreads();
-  unsigned long long lo = 0, hi = 0;  // token starts of this thread's block
-  const uint32_t bstart = p0 + tid * kBlockLen;
-  for (uint32_t q = ent[tid]; q < kBlockLen && bstart + q < M; q += adv[tid * kRowPad + q]) {
-    if (q < 64) lo |= 1ull << q; else hi |= 1ull << (q - 64);
+  if (tid < kBlocksPerSuper) {
+    unsigned long long lo = 0, hi = 0;  // token starts of this thread's block
+    const uint32_t bstart = p0 + tid * kBlockLen;
+    for (uint32_t q = ent[tid]; q < kBlockLen && bstart + q < M; q += adv[tid * kRowPad + q]) {
+      if (q < 64) lo |= 1ull << q; else hi |= 1ull << (q - 64);
+    }
+    uint4 out;
+    out.x = (uint32_t)lo; out.y = (uint32_t)(lo >> 32); out.z = (uint32_t)hi; out.w = (uint32_t)(hi >> 32);
+    *reinterpret_cast<uint4 *>(flags + (pos0 + bstart) / 32) = out;
+    *reinterpret_cast<uint4 *>(&fl[tid * 4]) = out;
   }
-  uint4 out;
-  out.x = (uint32_t)lo; out.y = (uint32_t)(lo >> 32); out.z = (uint32_t)hi; out.w = (uint32_t)(hi >> 32);
-  *reinterpret_cast<uint4 *>(flags + (imgs[img].pos0 + bstart) / 32) = out;
-}
-
-__device__ __forceinline__ uint32_t flag_at(const uint32_t *__restrict__ flags, uint64_t gpos) {
-  return (flags[gpos >> 5] >> (gpos & 31)) & 1u;
-}
-
-// =============================================================================================
-// Histograms (vp8l.h:516-535): LDS-private per block, merged into the image's 5x280 counters.
-// =============================================================================================
-// One count per active lane.  Lanes that all hold the same symbol (an opaque alpha channel, a flat
-// colour plane) would serialise on one LDS address: then one lane adds the number of lanes.  Otherwise the
-// lane adds to one of kHistCopies interleaved copies (equal symbols in one wave meet 4 times less often).
-constexpr uint32_t kHistCopies = 4;
-__device__ __forceinline__ void histo_add(uint32_t *h, uint32_t sym) {
-  const uint64_t active = __ballot(1);
-  const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym);
-  if (__ballot(sym == first) == active) {
-    if ((uint32_t)__builtin_ctzll(active) == (threadIdx.x & 63u)) atomicAdd(&h[first * kHistCopies], (uint32_t)__popcll(active));
-  } else {
-    atomicAdd(&h[sym * kHistCopies + (threadIdx.x & (kHistCopies - 1))], 1u);
-  }
-}
-
-__global__ __launch_bounds__(256) void k_histogram(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
-                                                   const uint32_t *__restrict__ sb_first, uint32_t n,
-                                                   const uint32_t *__restrict__ pix, const uint32_t *__restrict__ match,
-                                                   const uint32_t *__restrict__ flags, uint32_t *__restrict__ histo) {
-  __shared__ __attribute__((aligned(16))) uint32_t h[kNumCodes * kCodeStride * kHistCopies];
-  // one superblock per workgroup: the merge into the image's counters (up to 1400 global atomics) is paid once per 16384 positions
-  const uint32_t sb = blockIdx.x, img = find_image(sb_first, n, sb), tid = threadIdx.x;
-  const uint32_t M = st[img].M;
-  const uint32_t p0 = (sb - sb_first[img]) * kSuper;
-  if (p0 >= M) return;
-  for (uint32_t i = tid; i < kNumCodes * kCodeStride * kHistCopies; i += 256) h[i] = 0;
+  if (!histo) return;  // the coder with several groups counts by itself
   __syncthreads();
-  const uint64_t pos0 = imgs[img].pos0;
-  // four consecutive positions per thread, everything loaded before anything is used (the arrays have
-  // readable slack past M): dependent flag -> match -> pixel loads would leave the kernel latency-bound
+  uint32_t *h = reinterpret_cast<uint32_t *>(adv);
+  for (uint32_t i = tid; i < kHistWords; i += kMarkThreads) h[i] = 0;
+  __syncthreads();
+  // four consecutive positions per thread, everything loaded before anything is used (the arrays have readable slack past M)
 #pragma unroll 2
-  for (uint32_t k = 0; k < kSuper / 1024; k++) {
-    const uint32_t p = p0 + (k * 256 + tid) * 4;
+  for (uint32_t k = 0; k < kSuper / (4 * kMarkThreads); k++) {
+    const uint32_t o = (k * kMarkThreads + tid) * 4, p = p0 + o;
     if (p >= M) break;
+    uint32_t f4 = (fl[o >> 5] >> (o & 31)) & 15u;
+    if (p + 4 > M) f4 &= (1u << (M - p)) - 1u;
+    if (!f4) continue;
     const uint4 m4 = *reinterpret_cast<const uint4 *>(match + pos0 + p);
     const uint4 x4 = *reinterpret_cast<const uint4 *>(pix + pos0 + p);
-    uint32_t fl = (flags[(pos0 + p) >> 5] >> ((pos0 + p) & 31)) & 15u;
-    if (p + 4 > M) fl &= (1u << (M - p)) - 1u;
     const uint32_t mm[4] = {m4.x, m4.y, m4.z, m4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      if (!((fl >> j) & 1u)) continue;
+      if (!((f4 >> j) & 1u)) continue;
       const uint32_t m = mm[j], len = m & 0xff;
       if (len == 0) {
         const uint32_t px = xx[j];
@@ -1039,19 +1037,22 @@ __global__ __launch_bounds__(256) void k_histogram(const EncImage *__restrict__ 
       } else {
         uint32_t sym, nb, eb;
         prefix_encode(len, sym, nb, eb);
-        atomicAdd(&h[(kGreen * kCodeStride + 256 + sym) * kHistCopies + (tid & (kHistCopies - 1))], 1u);
+        atomicAdd(&h[(kGreen * kCodeStride + 256 + sym) * kHistCopies + (tid % kHistCopies)], 1u);
         prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);  // distance code, computed with the match
-        atomicAdd(&h[(kDist * kCodeStride + sym) * kHistCopies + (tid & (kHistCopies - 1))], 1u);
+        atomicAdd(&h[(kDist * kCodeStride + sym) * kHistCopies + (tid % kHistCopies)], 1u);
       }
     }
   }
   __syncthreads();
   uint32_t *g = histo + (size_t)img * kNumCodes * kCodeStride;
-  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) {
-    const uint4 c = *reinterpret_cast<const uint4 *>(&h[i * kHistCopies]);
-    const uint32_t v = c.x + c.y + c.z + c.w;
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += kMarkThreads) {
+    const uint32_t v = h[i * kHistCopies] + h[i * kHistCopies + 1] + h[i * kHistCopies + 2];
     if (v) atomicAdd(&g[i], v);
   }
+}
+
+__device__ __forceinline__ uint32_t flag_at(const uint32_t *__restrict__ flags, uint64_t gpos) {
+  return (flags[gpos >> 5] >> (gpos & 31)) & 1u;
 }
 
 // =============================================================================================
@@ -1621,6 +1622,15 @@ struct vp8l_encoder {
   double stage_seconds[9] = {};
 };
 
+// Heuristics of the candidate-list kernel (when a tile goes to the exhaustive kernel instead); VP8L_TUNE="per_value,budget,max_bucket"
+// overrides them for measurements.
+static uint32_t g_tune[3] = {kSpMaxPerValue, kSpBudget, kSpMaxBucket};
+static const bool g_tune_read = [] {
+  const char *v = getenv("VP8L_TUNE");
+  if (v) sscanf(v, "%u,%u,%u", &g_tune[0], &g_tune[1], &g_tune[2]);
+  return true;
+}();
+
 // The device arrays one encode call works in (a context's grow-only workspace, or parts of the static scratch array).
 struct EncBuffers {
   EncImage *imgs;
@@ -1670,14 +1680,16 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   mark(2);
   if (match_mode == 0)
     hipLaunchKernelGGL(k_lz77_sparse, dim3((gsb * (kSuper / kSpTile) + 7) / 8 * 8), dim3(kSpThreads), 0, s, B.imgs, B.st, B.sbf, nl,
-                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense);
+                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0], g_tune[1], g_tune[2]);
   mark(9);  // also when the candidate-list kernel is switched off
   hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,
                      match_mode == 0 ? B.dense : (const uint8_t *)nullptr);
   mark(3);
   hipLaunchKernelGGL(k_parse_exits, dim3(gsb), dim3(128), 0, s, B.imgs, B.st, B.sbf, nl, B.adv8, B.sx);
   hipLaunchKernelGGL(k_parse_chain, dim3(nl), dim3(256), 0, s, B.st, B.sbf, B.sx, B.entry);
-  hipLaunchKernelGGL(k_parse_mark, dim3(gsb), dim3(128), 0, s, B.imgs, B.st, B.sbf, nl, B.adv8, B.entry, B.flags);
+  const bool ext_on = extp && extp->on;
+  hipLaunchKernelGGL(k_parse_mark, dim3(gsb), dim3(kMarkThreads), 0, s, B.imgs, B.st, B.sbf, nl, B.adv8, B.entry, B.flags, B.pix, B.match,
+                     ext_on ? (uint32_t *)nullptr : B.histo);
   mark(4);
   ExtArgs ext;
   memset(&ext, 0, sizeof(ext));
@@ -1707,8 +1719,7 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
     mark(7);
     hipLaunchKernelGGL(k_ext_emit, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.gbits, B.uoff, d_out, ext);
   } else {
-  hipLaunchKernelGGL(k_histogram, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.histo);
-  mark(5);
+  mark(5);  // the symbols were counted by k_parse_mark
   hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.histo, B.tables, B.modes, B.elems, d_out, standard, ext);
   mark(6);
   hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables, B.gbits, B.ubits);
