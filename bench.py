@@ -50,8 +50,9 @@ def stage_bytes_per_pixel(bpp):
         "palette": 4.0,                      # every pixel read once (photo-like images stop after a few hundred pixels per block)
         "transform": 8.0,                    # only images the match kernel does not transform itself
         "match": 13.0,                       # 4 read; residual 4 + match 4 + advance 1 written
-        "parse": 2.0 + 1.0 / 8 + 1.0 / 128,  # advances read twice, token-start bits written, block exits
-        "histogram": 8.0 + 1.0 / 8,          # residual + match + token-start bits read
+        # advances read twice, block exits, token-start bits written; residual + match read to count the symbols
+        "parse": 2.0 + 1.0 / 8 + 1.0 / 128 + 8.0,
+        "histogram": 0.0,                    # the default coder counts inside "parse"; only the extended coder has this stage
         "header": 0.0,                       # per image, not per pixel
         "bitcount_scan": 8.0 + 2.0 / 8,      # residual + match + bits read, bit counts per 16 positions written
         "emit": 8.0 + 2.0 / 8 + bpp / 8.0,   # the same read again, the stream written
@@ -214,6 +215,8 @@ def _stage_table(stage_ms, bpp, npx_total):
         if name not in per_px:
             continue
         b = per_px[name]
+        if b == 0.0 and name != "header":
+            continue
         total_bytes += b
         gbs = b * npx_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         rows.append({"stage": name, "alg_bytes_per_px": round(b, 4), "ms": ms, "GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
