@@ -43,12 +43,18 @@ from webp_amd import sharding  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 
 
-def stage_bytes_per_pixel(bpp):
+def stage_bytes_per_pixel(bpp, palette_share=0.0, predictor=False):
     """Algorithmic HBM bytes per coded pixel of every encode stage (reads + writes each stage cannot avoid given the
-    arrays it is handed), keyed like Encoder.last_stage_seconds()."""
+    arrays it is handed), keyed like Encoder.last_stage_seconds().  palette_share: the share of the pixels that belongs to
+    palette images (only those are scanned to the end and go through k_transform; the others leave the palette scan after a
+    few hundred pixels per block and get their residual from the match kernel).  predictor: the predictor transform runs."""
+    if predictor:
+        transform = 8.0 + 4.0 + 8.0       # subtract green (4 + 4), mode choice (4 read), residual (4 + 4)
+    else:
+        transform = 8.0 * palette_share   # indices: 4 read, at most 4 written
     return {
-        "palette": 4.0,                      # every pixel read once (photo-like images stop after a few hundred pixels per block)
-        "transform": 8.0,                    # only images the match kernel does not transform itself
+        "palette": 4.0 * palette_share,
+        "transform": transform,
         "match": 13.0,                       # 4 read; residual 4 + match 4 + advance 1 written
         # advances read twice, block exits, token-start bits written; residual + match read to count the symbols
         "parse": 2.0 + 1.0 / 8 + 1.0 / 128 + 8.0,
@@ -208,16 +214,17 @@ def workload_decode1080p(args, world, rank, local_rank, dev):
     return out
 
 
-def _stage_table(stage_ms, bpp, npx_total):
-    per_px = stage_bytes_per_pixel(bpp)
+def _stage_table(stage_ms, bpp, npx_total, palette_share=0.0, predictor=False):
+    per_px = stage_bytes_per_pixel(bpp, palette_share, predictor)
     rows, total_bytes = [], 0.0
     for name, ms in stage_ms.items():
-        if name not in per_px:
+        if name not in per_px or name == "histogram":
             continue
         b = per_px[name]
-        if b == 0.0 and name != "header":
-            continue
         total_bytes += b
+        if b == 0.0:  # nothing per pixel to move (per-image work, or a stage these images leave at once): no rate to quote
+            rows.append({"stage": name, "alg_bytes_per_px": 0.0, "ms": ms, "GBps": None, "frac": None})
+            continue
         gbs = b * npx_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         rows.append({"stage": name, "alg_bytes_per_px": round(b, 4), "ms": ms, "GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
     ideal = 4.0 + bpp / 8.0
@@ -275,7 +282,8 @@ def _encode_workload(args, world, rank, local_rank, dev, w, h, plan, workload, m
     alg = (4.0 + bpp / 8.0) * batch * npx  # the fused ideal: every pixel read once, the stream written once
     n = len(dev_times)
     stage_ms = {k2: 1e3 * v / n for k2, v in stage_acc.items()}
-    rows, sums = _stage_table(stage_ms, bpp, batch * npx)
+    palette_share = sum(1 for m, _, _ in plan if m == 5) / float(batch)
+    rows, sums = _stage_table(stage_ms, bpp, batch * npx, palette_share, bool(predictor_bits))
     out = _base_line(args, world, metric, total_px / 1e6 / elapsed, elapsed, workload,
                      {"bits_per_pixel": bpp, "roundtrip_verified": ok, "decode": decode, "device_ms_per_step": 1e3 * dev_s,
                       "stage_ms_per_step": stage_ms, "roofline_stages": rows, "encode_bytes_per_pixel": sums,
