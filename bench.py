@@ -105,6 +105,11 @@ def cpu_baseline(w, h, plan, threads, budget_images):
     }
 
 
+# VP8L_BENCH_SHARE_GPU=1: ranks may share GPUs and talk over gloo -- only to rehearse `--gpus N` where N GPUs are not at hand;
+# the figures of such a run mean nothing.
+SHARE_GPU = os.environ.get("VP8L_BENCH_SHARE_GPU") == "1"
+
+
 def _fence(world):
     torch.cuda.synchronize()
     if world > 1:
@@ -129,7 +134,7 @@ def _timed_steps(args, world, dev, step, units_per_step):
         step()
     _fence(world)
     elapsed = time.perf_counter() - t0
-    return sharding.global_throughput(units_per_step * args.steps, elapsed, dev)
+    return sharding.global_throughput(units_per_step * args.steps, elapsed, None if SHARE_GPU else dev)
 
 
 def _base_line(args, world, metric, value, elapsed, workload, extra):
@@ -424,7 +429,7 @@ def workload_encode4k(args, world, rank, local_rank, dev):
     _fence(world)
     elapsed = time.perf_counter() - t0
     assert (status == 0).all(), status
-    total_px, elapsed = sharding.global_throughput(batch * npx * args.steps, elapsed, dev)
+    total_px, elapsed = sharding.global_throughput(batch * npx * args.steps, elapsed, None if SHARE_GPU else dev)
 
     total_bytes = int(lens.sum())
     bpp = 8.0 * total_bytes / (batch * npx)
@@ -516,7 +521,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # not under a launcher: start one rank per GPU ourselves, before anything here touches a GPU
         have = torch.cuda.device_count()   # counting devices does not initialise the GPU
-        if have < args.gpus:
+        if have < args.gpus and not SHARE_GPU:
             sys.exit("bench.py: --gpus %d but only %d device(s) visible" % (args.gpus, have))
         rc, out0 = sharding.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
         sys.stdout.write(out0)
@@ -525,9 +530,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if SHARE_GPU:  # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks: every rank uses a GPU that exists
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if SHARE_GPU:
+            dist.init_process_group("gloo")  # RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     fn = workload_encode4k if args.workload == "encode4k" else OTHER_WORKLOADS[args.workload]
     out = fn(args, world, rank, local_rank, dev)
