@@ -331,8 +331,10 @@ int ora_huffman_build(const uint32_t *histo, int n, int max_len, uint8_t *length
   int *order = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)); /* roots sorted ascending by weight */
   int nn = 0, nroots = 0;
   if (!nodes || !order) { free(nodes); free(order); return ORA_NOMEM; }
-  memset(lengths, 0, (size_t)n);
-  memset(codes, 0, sizeof(uint32_t) * (size_t)n);
+  if (n > 0) {
+    memset(lengths, 0, (size_t)n);
+    memset(codes, 0, sizeof(uint32_t) * (size_t)n);
+  }
   for (int s = 0; s < n; s++) {
     if (!histo[s]) continue;
     nodes[nn].w = histo[s]; nodes[nn].left = nodes[nn].right = -1; nodes[nn].sym = s;
@@ -1117,9 +1119,12 @@ typedef struct {
   uint32_t group;
 } xtoken;
 
+/* stray_cache: test vectors for decoders only.  Every stray_cache-th literal becomes a colour-cache token with an index
+ * that has nothing to do with the pixel (slots nobody wrote included), so the stream no longer decodes to the input; what
+ * it decodes to is defined by vp8l.h:315-324 all the same, and two decoders must agree on it. */
 static int write_general_image(bitw *w, const uint32_t *data, uint32_t n, uint32_t xsize,
                                uint32_t cache_bits, const uint32_t *meta, uint32_t meta_bits,
-                               uint32_t meta_xsize, uint32_t ngroups) {
+                               uint32_t meta_xsize, uint32_t ngroups, uint32_t stray_cache) {
   uint32_t cache_size = cache_bits ? 1u << cache_bits : 0;
   int green_n = 280 + (int)cache_size;
   uint32_t *cache = cache_size ? (uint32_t *)calloc(cache_size, sizeof(uint32_t)) : NULL;
@@ -1134,6 +1139,9 @@ static int write_general_image(bitw *w, const uint32_t *data, uint32_t n, uint32
     else if (cache && cache[cache_key(data[p], cache_bits)] == data[p]) {
       tok[ntok].kind = 2; tok[ntok].a = cache_key(data[p], cache_bits); tok[ntok].b = 0; adv = 1;
     } else { tok[ntok].kind = 0; tok[ntok].a = data[p]; tok[ntok].b = 0; adv = 1; }
+    if (cache && stray_cache && tok[ntok].kind == 0 && ntok % stray_cache == 0) {
+      tok[ntok].kind = 2; tok[ntok].a = (uint32_t)((ntok * 7 + 3) % cache_size);
+    }
     tok[ntok++].group = g;
     if (cache) for (uint32_t i = 0; i < adv; i++) cache[cache_key(data[p + i], cache_bits)] = data[p + i];
     p += adv;
@@ -1202,7 +1210,7 @@ static int write_general_image(bitw *w, const uint32_t *data, uint32_t n, uint32
 /* entropy_image := cache_info huffman_group pixels (vp8l.h:161-173); written without a cache */
 static int write_sub_image(bitw *w, const uint32_t *data, uint32_t n, uint32_t xsize) {
   bw_put(w, 0, 1);
-  return write_general_image(w, data, n, xsize, 0, NULL, 0, 0, 1);
+  return write_general_image(w, data, n, xsize, 0, NULL, 0, 0, 1, 0);
 }
 
 int ora_encode_ext(const uint32_t *argb, uint32_t w, uint32_t h, const ora_ext_params *prm,
@@ -1324,7 +1332,8 @@ int ora_encode_ext(const uint32_t *argb, uint32_t w, uint32_t h, const ora_ext_p
       bw_put(&bw, 0, 1);
     }
     if (rc == ORA_OK)
-      rc = write_general_image(&bw, img, (uint32_t)((size_t)xsize * h), xsize, cache_bits, meta, mbits, mxs, ngroups);
+      rc = write_general_image(&bw, img, (uint32_t)((size_t)xsize * h), xsize, cache_bits, meta, mbits, mxs, ngroups,
+                               prm->stray_cache > 0 ? (uint32_t)prm->stray_cache : 0u);
     free(meta);
   }
   free(img);

@@ -123,6 +123,8 @@ typedef struct {
   int meta_groups;         /* number of Huffman groups when meta_bits != 0 */
   int transform_order;     /* permutation selector for the order transforms are written */
   const uint32_t *meta_image;      /* Huffman group of every tile of the entropy image, or NULL = synthetic pattern */
+  int stray_cache;         /* n > 0: every n-th literal of the main image becomes a cache token with an unrelated index
+                            * (decoder test vectors: such a stream does not decode to the input) */
 } ora_ext_params;
 
 int ora_encode_ext(const uint32_t *argb, uint32_t w, uint32_t h, const ora_ext_params *prm,

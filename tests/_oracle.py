@@ -39,6 +39,7 @@ class ExtParams(C.Structure):
         ("predictor_modes", C.c_void_p), ("color_bits", C.c_int), ("color_elems", C.c_void_p),
         ("use_palette", C.c_int), ("cache_bits", C.c_int), ("meta_bits", C.c_int),
         ("meta_groups", C.c_int), ("transform_order", C.c_int), ("meta_image", C.c_void_p),
+        ("stray_cache", C.c_int),
     ]
 
 

@@ -118,6 +118,61 @@ def test_corrupt_streams_get_the_oracle_verdict():
     assert accepted > 20
 
 
+def test_corrupt_colour_cache_streams_get_the_oracle_verdict():
+    # The workgroup form resolves cache tokens from keys alone; a damaged stream may ask for a slot that was never written
+    # (the one case where a pixel's key is not its token's index), chain cache tokens through copies, or cut them short.
+    rng = np.random.default_rng(4242)
+    bases = []
+    for (w, h, mode, prm) in ((130, 90, 4, dict(cache_bits=4)), (130, 90, 4, dict(cache_bits=11, use_subtract_green=1)),
+                              (97, 61, 5, dict(cache_bits=2)), (64, 64, 3, dict(cache_bits=7, meta_bits=3, meta_groups=4)),
+                              (200, 40, 4, dict(cache_bits=1, predictor_bits=3))):
+        img = O.gen_image(mode, w, h, 9, 40)
+        rc, s = O.encode_ext(img, w, h, **prm)
+        assert rc == 0
+        bases.append(s)
+    streams = list(bases)
+    for base in bases:
+        for it in range(120):
+            b = bytearray(base)
+            if it % 4 == 0:
+                b = b[: int(rng.integers(9, len(b)))]
+            else:
+                for _ in range(int(rng.integers(1, 3))):
+                    pos = int(rng.integers(len(b) // 4, len(b)))   # mostly inside the pixel data
+                    b[pos] ^= 1 << int(rng.integers(0, 8))
+            streams.append(bytes(b))
+    res = gpu_decode_all(streams)
+    accepted = 0
+    for s, (st, arr, w, h) in zip(streams, res):
+        rc0, ref, w0, h0 = O.decode(s)
+        assert st == rc0, (st, rc0, len(s))
+        if rc0 == 0:
+            assert np.array_equal(arr, ref)
+            accepted += 1
+    assert accepted > 50
+
+
+def test_cache_tokens_with_unrelated_indices():
+    # Test vectors in which cache tokens ask for arbitrary slots, written or not: what they decode to is defined (an unwritten
+    # slot holds 0, and that pixel is then stored under the key of 0, not under the index asked for); the oracle says what.
+    streams, want = [], []
+    for (w, h, mode) in ((130, 90, 4), (64, 64, 3), (300, 200, 4), (97, 61, 5)):
+        img = O.gen_image(mode, w, h, 21, 60)
+        for prm in (dict(cache_bits=1), dict(cache_bits=4), dict(cache_bits=11), dict(cache_bits=6, meta_bits=3, meta_groups=3),
+                    dict(cache_bits=5, predictor_bits=3, use_subtract_green=1)):
+            for every in (1, 2, 5, 17):
+                rc, s = O.encode_ext(img, w, h, stray_cache=every, **prm)
+                assert rc == 0
+                rc0, ref, _, _ = O.decode(s)
+                assert rc0 == 0
+                streams.append(s)
+                want.append(ref)
+    res = gpu_decode_all(streams)
+    for k, ((st, arr, w, h), ref) in enumerate(zip(res, want)):
+        assert st == 0, (k, st)
+        assert np.array_equal(arr, ref), k
+
+
 def test_encode_then_decode_on_device():
     import torch
     w, h = 640, 360

@@ -193,6 +193,20 @@ def test_decoder_core_on_extended_streams(K, prm, shape, mode):
     assert np.array_equal(out, ref) and np.array_equal(out, img)
 
 
+@pytest.mark.parametrize("cache_bits", [1, 4, 11])
+@pytest.mark.parametrize("every", [1, 3])
+def test_decoder_core_on_cache_tokens_with_unrelated_indices(K, cache_bits, every):
+    # cache tokens that ask for arbitrary slots (also unwritten ones): defined output, not the input
+    w, h = 97, 61
+    img = O.gen_image(4, w, h, 21, 60)
+    rc, data = O.encode_ext(img, w, h, cache_bits=cache_bits, stray_cache=every)
+    assert rc == 0
+    rc0, ref, _, _ = O.decode(data)
+    rc, out, ww, hh = core_decode(K, data, w, h)
+    assert rc == rc0 == 0
+    assert np.array_equal(out, ref) and not np.array_equal(out, img)
+
+
 def test_decoder_core_error_parity_on_corrupt_streams(K):
     """Same verdict as the oracle on damaged streams, and the same pixels whenever both accept."""
     rng = np.random.default_rng(77)

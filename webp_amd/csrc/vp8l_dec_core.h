@@ -252,7 +252,8 @@ struct DecAccel {
   // the driver decodes the pixels of one-group, cache-less coded images itself (kEvPixels): it must
   // leave st.fill = st.total, the bit reader state and st.phase = st.after (or a failure) behind
   bool driver_pixels = false;
-  bool driver_multi = false;  // ... also those with several Huffman groups (still no colour cache)
+  bool driver_multi = false;  // ... also those with several Huffman groups
+  bool driver_cache = false;  // ... also those with a colour cache
   bool on = false;  // win, ring and g0 are set (tested instead of the pointers)
 };
 constexpr uint32_t kInlineCopyMax = 16;   // longer copies go to the driver (kEvCopy)
@@ -492,7 +493,7 @@ VP8L_HD uint32_t dec_step(DecState &st, const DecAccel &acc = DecAccel()) {
         break;
       }
       case kPhPixels: {
-        if (acc.driver_pixels && (st.ngroups == 1 || acc.driver_multi) && st.cache_bits == 0 && st.fill == 0 && st.total < 0x7fffffffu) {
+        if (acc.driver_pixels && (st.ngroups == 1 || acc.driver_multi) && (st.cache_bits == 0 || acc.driver_cache) && st.fill == 0 && st.total < 0x7fffffffu) {
           VP8L_SAVE_BR();
           return kEvPixels;
         }

@@ -384,6 +384,12 @@ constexpr uint32_t kWgJumpSteps = 12;         // source chains are at most 2048 
 static_assert(kWgSpan + 128 <= kWgWindow * 8 / 2, "a span fits the window with room to move");
 static_assert(kWgLongSlots % kWgLongBatch == 0 && kWgLongSlots >= kWgLongLens, "long-code slots");
 
+// Colour cache (vp8l.h:286-324) in the workgroup form.
+struct WgCacheShared {
+  uint32_t last[1u << kMaxCacheBits];  // per cache slot: 1 + the last pixel of the round with that key (0: none); all zero between uses
+  uint16_t key[kWgNear];               // cache key of every pixel of the round
+};
+
 struct WgShared {
   uint32_t srcp[kWgNear];                     // per pixel of the round: the position its value comes from (| kFinal)
   uint32_t changed[kWgJumpSteps];
@@ -395,7 +401,7 @@ struct WgShared {
   //   base + (code as a number) = index of the symbol in `sorted`
   uint32_t lim[kNumCodes][kWgLongSlots];
   uint32_t base[kNumCodes][kWgLongSlots];
-  uint32_t defer_off, defer_px, end_off, end_px;
+  uint32_t defer_off, defer_px, end_off, end_px, cut_off;
   int32_t status;
   uint32_t s_bits, s_fill, s_flushed;         // what the uniform path did
   uint16_t sorted[kWgSorted];                 // symbols in code order
@@ -414,9 +420,11 @@ __device__ __forceinline__ void wg_window_load(VP8L_LDS uint32_t *win, const Dec
 }
 
 // One symbol at bit n of w (64 stream bits) by one thread; false when w does not hold all of it.
+// far: the group's whole symbol list in HBM, for alphabets that the LDS copy does not hold (a green code with colour-cache
+// symbols); null: the LDS copy.
 template <class Sh>
 __device__ __forceinline__ bool wg_sym(uint64_t w, uint32_t &n, const VP8L_LDS HuffTable &t, const VP8L_LDS Sh &sh, uint32_t code,
-                                       uint32_t &sym) {
+                                       uint32_t &sym, const uint16_t *far = nullptr) {
   if (n > 64 - kLutBits) return false;
   const uint32_t bits = (uint32_t)(w >> n);
   const uint32_t e = t.lut[bits & ((1u << kLutBits) - 1u)];
@@ -435,7 +443,8 @@ __device__ __forceinline__ bool wg_sym(uint64_t w, uint32_t &n, const VP8L_LDS H
   }
   const uint32_t l = kLutBits + 1 + slot;
   if (slot >= kWgLongLens || n + l > 64) return false;
-  sym = sh.sorted[sh.base[code][slot] + (v >> (32 - l))];
+  const uint32_t at = sh.base[code][slot] + (v >> (32 - l));
+  sym = far ? far[at] : sh.sorted[at];
   n += l;
   return true;
 }
@@ -459,15 +468,25 @@ __device__ __forceinline__ void wg_prepare_long(VP8L_LDS Sh &sh, const VP8L_LDS 
 
 // The token that starts at bit 0 of w: hop = its bits (0: not decodable from w alone), cnt = pixels it
 // makes, val = the pixel (literal) or the distance (ref).
+// far (see wg_sym): set for images with a colour cache; a cache symbol then is a token of one pixel: cnt = 1, ref = true,
+// val = kWgCacheTok | index (the caller resolves it).
+constexpr uint32_t kWgCacheTok = 0x80000000u;  // no distance reaches this bit
 template <bool kValue = true, class Sh>
 __device__ __forceinline__ void wg_token(uint64_t w, const VP8L_LDS GroupTables &g, const VP8L_LDS Sh &sh, uint32_t xsize,
-                                         uint32_t &hop, uint32_t &cnt, uint32_t &val, bool &ref) {
+                                         uint32_t &hop, uint32_t &cnt, uint32_t &val, bool &ref, const uint16_t *far = nullptr) {
   hop = 0; cnt = 0; val = 0; ref = false;
   uint32_t n = 0, S = 0;
-  if (!wg_sym(w, n, g.t[kGreen], sh, kGreen, S)) return;
+  if (!wg_sym(w, n, g.t[kGreen], sh, kGreen, S, far)) return;
+  if (far && S >= 280) {
+    val = kWgCacheTok | (S - 280);
+    cnt = 1;
+    ref = true;
+    hop = n;
+    return;
+  }
   if (S < 256) {
     uint32_t r = 0, b = 0, a = 0;
-    if (!wg_sym(w, n, g.t[kRed], sh, kRed, r) || !wg_sym(w, n, g.t[kBlue], sh, kBlue, b) || !wg_sym(w, n, g.t[kAlpha], sh, kAlpha, a)) return;
+    if (!wg_sym(w, n, g.t[kRed], sh, kRed, r, far) || !wg_sym(w, n, g.t[kBlue], sh, kBlue, b, far) || !wg_sym(w, n, g.t[kAlpha], sh, kAlpha, a, far)) return;
     if (kValue) val = (a << 24) | (r << 16) | (S << 8) | b;
     cnt = 1;
     hop = n;
@@ -478,7 +497,7 @@ __device__ __forceinline__ void wg_token(uint64_t w, const VP8L_LDS GroupTables 
     const uint32_t length = base + (nb ? (uint32_t)(w >> n) & ((1u << nb) - 1u) : 0u);
     n += nb;
     uint32_t ds = 0;
-    if (!wg_sym(w, n, g.t[kDist], sh, kDist, ds)) return;
+    if (!wg_sym(w, n, g.t[kDist], sh, kDist, ds, far)) return;
     prefix_decode_base(ds, base, nb);
     if (n + nb > 64) return;
     const uint32_t dcode = base + (nb ? (uint32_t)(w >> n) & ((1u << nb) - 1u) : 0u);
@@ -494,11 +513,26 @@ __device__ __forceinline__ void wg_token(uint64_t w, const VP8L_LDS GroupTables 
 // Several Huffman groups (vp8l.h:250-256): the group is that of the tile in which a token STARTS, so a round runs with the tables of
 // the group at the current pixel and takes only the tokens that start before the next tile with another group; when the group
 // changes, that group's tables are copied from HBM into the same LDS place (a few words per thread).
+//
+// A colour cache (vp8l.h:286-324): a cache symbol stands for the pixel last stored under its index, and every pixel is stored
+// under the key of its value.  The key of a cache token's pixel is its index (whatever was stored there has that key), the key
+// of a copied pixel is that of its source, so after the sources are resolved every pixel of the round has a key although the
+// cache tokens' values are still unknown.  A cache token then takes the round's last earlier pixel with its key as its source
+// (a wave looks back over the keys 64 at a time), or the slot's value from before the round, and a second round of source
+// jumping gives every pixel its value.  The slots are updated with the round's last pixel of every key.  One case breaks the
+// "key = index" rule: a slot that was never written holds 0, whose key is 0; a token that asks for such a slot (no valid
+// encoder does) ends the round before it and is decoded by wave 0 on its own.
 __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, VP8L_LDS GroupTables *g_, VP8L_LDS uint32_t *ring,
-                                              VP8L_LDS uint32_t *win, VP8L_LDS WgShared *sh_, const DecImage &im, uint32_t tid) {
+                                              VP8L_LDS uint32_t *win, VP8L_LDS WgShared *sh_, VP8L_LDS WgCacheShared *cs_,
+                                              const DecImage &im, uint32_t tid) {
   VP8L_LDS DecState &st = *st_;
   VP8L_LDS GroupTables &g = *g_;
   VP8L_LDS WgShared &sh = *sh_;
+  VP8L_LDS WgCacheShared &cs = *cs_;
+  const uint32_t cb = st.cache_bits;
+  uint32_t *cache = st.cache;  // HBM (L2): 1 << cb slots, zeroed when the image began
+  constexpr uint32_t kPend = 0x40000000u, kRoot = 0x20000000u;  // in srcp: a cache token's pixel (| index) / a copy of one (| its place in the round)
+  if (cb) for (uint32_t i = tid; i < (1u << kMaxCacheBits); i += kWgThreads) cs.last[i] = 0;  // a barrier follows before the first use
   const bool multi = st.ngroups > 1;
   const uint32_t *meta = st.meta;
   const uint32_t mbits = st.meta_bits, mxs = st.meta_xsize, width = st.xsize, rows = st.ysize;
@@ -567,8 +601,9 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, VP8L_LDS G
       const uint32_t a = (uint32_t)(P - win_bit0) + tid, idx = a >> 5, sft = a & 31u;
       const uint64_t x = (uint64_t)win[idx] | ((uint64_t)win[idx + 1] << 32);
       const uint64_t w = sft ? (x >> sft) | ((uint64_t)win[idx + 2] << (64 - sft)) : x;
-      wg_token(w, g, sh, xsize, hop, cnt, val, ref);
+      wg_token(w, g, sh, xsize, hop, cnt, val, ref, cb ? g.sorted : (const uint16_t *)nullptr);
     }
+    const bool cch = ref && (val & kWgCacheTok);  // a colour-cache token (only with cb != 0)
     // ---- 2. jump tables next^(4^k) for k < 4, then the marks
     // Every step costs an LDS round trip and a barrier whatever it does, so a step quadruples the jump:
     // s1/s2/s3[k] are 1, 2 and 3 jumps of 4^k tokens from this offset, the fourth is the next table's entry.
@@ -609,7 +644,7 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, VP8L_LDS G
     const uint32_t c = on && hop ? cnt : 0u;
     const uint32_t incl = wave_incl_scan_u32(c, (int)lane);
     if (lane == 63) sh.wsum[wave] = incl;
-    if (tid == 0) { sh.defer_off = 0xffffffffu; sh.end_off = 0; sh.end_px = 0; }
+    if (tid == 0) { sh.defer_off = 0xffffffffu; sh.cut_off = 0xffffffffu; sh.end_off = 0; sh.end_px = 0; }
     __syncthreads();
     // the waves' sums, scanned by every wave for itself
     const uint32_t wsums = wave_incl_scan_u32(lane < kWgWaves ? sh.wsum[lane] : 0u, (int)lane);
@@ -633,6 +668,8 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, VP8L_LDS G
           // (tokens lie in stream order, so the smallest offset is the first; offset and pixels in one word)
           __hip_atomic_fetch_min(&sh.defer_off, (tid << 16) | (ex < 0xffffu ? ex : 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (ex + cnt > room && ex <= room && ex < span_px && room == left && ex < room) sh.status = kErrInvalidVp8l;  // a reference that runs past the end of the image
+        } else if (cch) {
+          sh.srcp[ex] = kPend | (val & 0xffffu);
         } else if (!ref) {
           ring[pos & kMask] = val;
           sh.srcp[ex] = pos | kFinal;
@@ -678,38 +715,133 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, VP8L_LDS G
     status = sh.status;
     if (status != kOk) break;
     const bool deferred = sh.defer_off != 0xffffffffu;
-    const uint32_t adv = deferred ? sh.defer_off >> 16 : sh.end_off, produced = deferred ? sh.defer_off & 0xffffu : sh.end_px;
+    uint32_t adv = deferred ? sh.defer_off >> 16 : sh.end_off, produced = deferred ? sh.defer_off & 0xffffu : sh.end_px;
     // Sources that are made by a reference of this round are replaced by that pixel's source until every pixel
     // points at a final one: chains of references (a run coded as copies of 1, 2, 4, 8 ... pixels) take
     // log2(chain length) steps instead of one copy after the other.  A source read while its owner replaces
     // it is the old or the new value; both are sources of the same pixel value.
-    for (uint32_t it = 0; it < kWgJumpSteps; it++) {
-      bool open = false;
+    // (With a colour cache a chain may also end at a cache token's pixel, kPend, whose value comes later: the pixels that
+    // copy it remember where it is, kRoot.)
+    auto jump_sources = [&]() {
+      for (uint32_t it = 0; it < kWgJumpSteps; it++) {
+        bool open = false;
 #pragma unroll
-      for (uint32_t k = 0; k < kWgNear / kWgThreads; k++) {
-        const uint32_t q = k * kWgThreads + tid;
-        if (q < produced) {
-          const uint32_t v = sh.srcp[q];
-          if (!(v & kFinal)) {
-            const uint32_t t = sh.srcp[v - fill];
-            sh.srcp[q] = t;
-            open = open || !(t & kFinal);
+        for (uint32_t k = 0; k < kWgNear / kWgThreads; k++) {
+          const uint32_t q = k * kWgThreads + tid;
+          if (q < produced) {
+            const uint32_t v = sh.srcp[q];
+            if (!(v & (kFinal | kPend | kRoot))) {
+              uint32_t t = sh.srcp[v - fill];
+              if (t & kPend) t = kRoot | (v - fill);
+              sh.srcp[q] = t;
+              open = open || !(t & (kFinal | kRoot));
+            }
           }
         }
+        if (open) sh.changed[it] = 1;
+        __syncthreads();
+        if (!sh.changed[it]) break;
       }
-      if (open) sh.changed[it] = 1;
-      __syncthreads();
-      if (!sh.changed[it]) break;
-    }
+    };
+    jump_sources();
 #pragma unroll
     for (uint32_t k = 0; k < kWgNear / kWgThreads; k++) {
       const uint32_t q = k * kWgThreads + tid;
       if (q < produced) {
-        const uint32_t s = sh.srcp[q] & ~kFinal;
-        if (s != fill + q) ring[(fill + q) & kMask] = s + kWgNear >= fill ? ring[s & kMask] : dst[s];
+        const uint32_t sv = sh.srcp[q], s = sv & ~kFinal;
+        if ((sv & kFinal) && s != fill + q) ring[(fill + q) & kMask] = s + kWgNear >= fill ? ring[s & kMask] : dst[s];
       }
     }
     __syncthreads();
+    if (cb) {
+      // ---- keys of all pixels of the round; pixels whose value is in the ring now point at themselves
+      uint32_t mykey[kWgNear / kWgThreads];
+#pragma unroll
+      for (uint32_t k = 0; k < kWgNear / kWgThreads; k++) {
+        const uint32_t q = k * kWgThreads + tid;
+        mykey[k] = 0;
+        if (q < produced) {
+          const uint32_t sv = sh.srcp[q];
+          if (sv & kFinal) mykey[k] = cache_key(ring[(fill + q) & kMask], cb);
+          else if (sv & kPend) mykey[k] = sv & 0xffffu;
+          else mykey[k] = sh.srcp[sv & 0xffffu] & 0xffffu;  // kRoot: the key of the cache token it copies
+          cs.key[q] = (uint16_t)mykey[k];
+        }
+      }
+      if (tid < kWgJumpSteps) sh.changed[tid] = 0;
+      __syncthreads();
+#pragma unroll
+      for (uint32_t k = 0; k < kWgNear / kWgThreads; k++) {
+        const uint32_t q = k * kWgThreads + tid;
+        if (q < produced) {
+          const uint32_t sv = sh.srcp[q];
+          if (sv & kFinal) sh.srcp[q] = (fill + q) | kFinal;
+          else if (sv & kRoot) sh.srcp[q] = fill + (sv & 0xffffu);  // an open source again: the cache token's pixel
+        }
+      }
+      // ---- every cache token: the round's last earlier pixel with its key, else the slot as it was before the round
+      const bool mine = on && hop && cch && ex < produced;
+      uint32_t found = 0xffffffffu;
+      for (uint64_t m = __ballot(mine); m; m &= m - 1) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(m);
+        const uint32_t q0 = lane_read(ex, l), k0 = lane_read(val & 0xffffu, l);
+        uint32_t f = 0xffffffffu;
+        for (int base = (int)q0 - 1; base >= 0; base -= 64) {
+          const int i = base - (int)lane;
+          const uint64_t hit = __ballot(i >= 0 && cs.key[i] == k0);
+          if (hit) { f = (uint32_t)base - (uint32_t)__builtin_ctzll(hit); break; }
+        }
+        if (lane == l) found = f;
+      }
+      if (mine) {
+        const uint32_t idx = val & 0xffffu;
+        if (found != 0xffffffffu) {
+          sh.srcp[ex] = fill + found;
+        } else {
+          const uint32_t older = cache[idx];
+          if (cache_key(older, cb) != idx) {
+            // a slot nobody wrote: the pixel is 0 and does not have the key this round gave it; everything from here on waits
+            __hip_atomic_fetch_min(&sh.cut_off, (tid << 16) | ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            ring[pos & kMask] = older;
+            sh.srcp[ex] = pos | kFinal;
+          }
+        }
+      }
+      __syncthreads();
+      if (sh.cut_off != 0xffffffffu) { adv = sh.cut_off >> 16; produced = sh.cut_off & 0xffffu; }
+      jump_sources();
+#pragma unroll
+      for (uint32_t k = 0; k < kWgNear / kWgThreads; k++) {
+        const uint32_t q = k * kWgThreads + tid;
+        if (q < produced) {
+          const uint32_t s = sh.srcp[q] & ~kFinal;
+          if (s != fill + q) ring[(fill + q) & kMask] = ring[s & kMask];  // a pixel of this round, in the ring
+        }
+      }
+      __syncthreads();
+      // ---- the slots take the round's last pixel of every key
+      uint32_t myval[kWgNear / kWgThreads];
+#pragma unroll
+      for (uint32_t k = 0; k < kWgNear / kWgThreads; k++) {
+        const uint32_t q = k * kWgThreads + tid;
+        if (q < produced) {
+          myval[k] = ring[(fill + q) & kMask];
+          mykey[k] = cache_key(myval[k], cb);
+          __hip_atomic_fetch_max(&cs.last[mykey[k]], q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (uint32_t k = 0; k < kWgNear / kWgThreads; k++) {
+        const uint32_t q = k * kWgThreads + tid;
+        if (q < produced && cs.last[mykey[k]] == q + 1) {
+          cache[mykey[k]] = myval[k];
+          cs.last[mykey[k]] = 0;
+        }
+      }
+      __syncthreads();
+    }
     fill += produced;
     P += adv;
     {
@@ -734,18 +866,29 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, VP8L_LDS G
         const VP8L_LDS uint16_t *sorted = sh.sorted;
         uint32_t nfill = fill, nflushed = flushed;
         int32_t rc = kOk;
-        const uint32_t S = wb_sym(b, g.t[kGreen], sorted, lane);
-        if (S < 256) {
-          const uint32_t r2 = wb_sym(b, g.t[kRed], sorted, lane);
-          const uint32_t b2 = wb_sym(b, g.t[kBlue], sorted, lane);
-          const uint32_t a2 = wb_sym(b, g.t[kAlpha], sorted, lane);
-          if (lane == 0) ring[fill & kMask] = (a2 << 24) | (r2 << 16) | (S << 8) | b2;
+        // with a colour cache the symbol lists are longer than the LDS copy: the group's own list in HBM then
+        auto usym = [&](const VP8L_LDS HuffTable &t) { return cb ? wb_sym(b, t, g.sorted, lane) : wb_sym(b, t, sorted, lane); };
+        const uint32_t S = usym(g.t[kGreen]);
+        if (S < 256 || (cb && S >= 280)) {
+          uint32_t px;
+          if (S < 256) {
+            const uint32_t r2 = usym(g.t[kRed]);
+            const uint32_t b2 = usym(g.t[kBlue]);
+            const uint32_t a2 = usym(g.t[kAlpha]);
+            px = (a2 << 24) | (r2 << 16) | (S << 8) | b2;
+          } else {
+            px = uni(cache[S - 280]);  // vp8l.h:315-324; an index is below 1 << cb: the alphabet ends there
+          }
+          if (lane == 0) {
+            ring[fill & kMask] = px;
+            if (cb) cache[cache_key(px, cb)] = px;
+          }
           nfill = fill + 1;
         } else if (S < 280) {
           uint32_t base, nb;
           prefix_decode_base(S - 256, base, nb);
           const uint32_t length = base + wb_get(b, nb);
-          prefix_decode_base(wb_sym(b, g.t[kDist], sorted, lane), base, nb);
+          prefix_decode_base(usym(g.t[kDist]), base, nb);
           const uint32_t dcode = base + wb_get(b, nb);
           const uint32_t dist = code_to_dist(xsize & 0x7fffffffu, dcode, (xsize >> 31) != 0);
           if (dist > fill || length > total - fill) {
@@ -756,9 +899,22 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, VP8L_LDS G
               const uint32_t piece = length - c0 < 1024 ? length - c0 : 1024, start = fill + c0;
               for (uint32_t c2 = 0; c2 < piece; c2 += 64) {
                 const uint32_t e = c0 + c2 + lane;
-                if (c2 + lane < piece) {
+                const bool in = c2 + lane < piece;
+                uint32_t v = 0;
+                if (in) {
                   const uint32_t s = fill - dist + (dist >= length ? e : e % dist);
-                  ring[(fill + e) & kMask] = s + kWgNear >= start ? ring[s & kMask] : dst[s];
+                  v = s + kWgNear >= start ? ring[s & kMask] : dst[s];
+                  ring[(fill + e) & kMask] = v;
+                }
+                if (cb) {
+                  // the copied pixels enter the cache in order: of the 64 of this step the last one of every key stays
+                  // (this wave's LDS operations complete in order; the chunks follow each other)
+                  const uint32_t key = cache_key(v, cb);
+                  if (in) __hip_atomic_fetch_max(&cs.last[key], lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  if (in && cs.last[key] == lane + 1) {
+                    cache[key] = v;
+                    cs.last[key] = 0;
+                  }
                 }
               }
               const uint32_t upto = (start + piece) & ~63u;
@@ -771,7 +927,7 @@ __device__ __noinline__ void wg_decode_pixels(VP8L_LDS DecState *st_, VP8L_LDS G
             nfill = fill + length;
           }
         } else {
-          rc = kErrInvalidVp8l;  // no colour cache: no such symbol in a 280-symbol alphabet
+          rc = kErrInvalidVp8l;  // without a colour cache there is no such symbol in a 280-symbol alphabet
         }
         if (lane == 0) {
           sh.s_bits = 128 - b.cnt;
@@ -1577,6 +1733,7 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
   static_assert(sizeof(DecTableScratch) <= sizeof(uint32_t) * kWgRing, "the scratch fits under the ring");
   __shared__ uint32_t win[kWgWindowWords];
   __shared__ __attribute__((aligned(16))) WgShared sh;
+  __shared__ WgCacheShared cs;
   __shared__ uint32_t s_ev;
   const uint32_t img = blockIdx.x, tid = threadIdx.x;
   const DecImage im = imgs[img];
@@ -1588,6 +1745,7 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
   acc.g0 = &g0;
   acc.driver_pixels = true;
   acc.driver_multi = true;
+  acc.driver_cache = true;
   acc.on = true;
   if (tid == 0) {
     dec_init(st, im.data, im.len, im.out, im.aux, im.aux_cap, &g0, im.groups, im.group_cap, im.cache, &ros.scratch, im.sorted);
@@ -1601,7 +1759,7 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
     const uint32_t ev = s_ev;
     if (ev == kEvDone) break;
     if (ev == kEvPixels) {
-      if (im.par && st.dst == st.out && st.total >= kParMinPixels && st.ngroups == 1) {
+      if (im.par && st.dst == st.out && st.total >= kParMinPixels && st.ngroups == 1 && st.cache_bits == 0) {
         // the main image of a large stream: its pixels are decoded by the segment kernels that follow, from these tables
         ParImage *par = im.par;
         for (uint32_t i = tid; i < sizeof(GroupTables) / 4; i += kWgThreads)
@@ -1623,7 +1781,7 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
         break;
       }
       wg_decode_pixels((VP8L_LDS DecState *)&st, (VP8L_LDS GroupTables *)&g0, (VP8L_LDS uint32_t *)ros.ring,
-                       (VP8L_LDS uint32_t *)win, (VP8L_LDS WgShared *)&sh, im, tid);
+                       (VP8L_LDS uint32_t *)win, (VP8L_LDS WgShared *)&sh, (VP8L_LDS WgCacheShared *)&cs, im, tid);
     } else if (ev == kEvRefill) {
       const uint64_t lo = st.bytepos;
       wg_window_load((VP8L_LDS uint32_t *)win, im, lo, tid);
