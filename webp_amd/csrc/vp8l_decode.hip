@@ -1698,8 +1698,12 @@ __global__ __launch_bounds__(256) void k_par_jump(const DecImage *__restrict__ i
           // the source's own source, up to three steps on; read while its owner replaces it, it is the old or the new
           // one: both lead to the same literal
           uint32_t t = __hip_atomic_load(&srcg[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (!(t & kFinalBit)) t = __hip_atomic_load(&srcg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (!(t & kFinalBit)) t = __hip_atomic_load(&srcg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef VP8L_JUMP_HOPS
+#define VP8L_JUMP_HOPS 5
+#endif
+#pragma unroll
+          for (int hop = 1; hop < VP8L_JUMP_HOPS; hop++)
+            if (!(t & kFinalBit)) t = __hip_atomic_load(&srcg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&srcg[p], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           // a chain that has reached its literal (whose pixel the kernels before this one wrote) gives the pixel its value
           // here, once: the position is final from now on and no pass looks at it again
