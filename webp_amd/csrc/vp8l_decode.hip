@@ -1370,6 +1370,7 @@ constexpr uint32_t kLanePasses = 8;   // entries still changing after this many 
 constexpr uint32_t kLaneGuessRound = kLaneRounds * 3 / 4;             // the guess of a lane's exit starts here (from 1/2: 10.9 ms, 3/4: 9.5, 7/8: 9.8 per 1080p batch)
 constexpr uint32_t kLaneRecCap = kParRecCap / kLanesPerSeg;           // token records per lane: tokens of 4 bits fill them
 static_assert(4 + kLanesPerSeg <= 64, "a segment's slots hold the lanes' record counts");
+static_assert(kLaneRecCap % 2 == 0, "records are stored in pairs");
 static_assert(kLaneBits < kParSegBits && (kLanesPerSeg & (kLanesPerSeg - 1)) == 0 && kLanesPerSeg <= 64, "the lanes of a segment sit in one wave");
 static_assert(kLaneThreads % 64 == 0 && kLaneThreads >= kNumCodes * kWgLongSlots, "whole waves; one thread per long-code slot");
 static_assert(64 % kLaneChunkWords == 0 && kLaneBits % kLaneChunkBits == 0 && kLaneBits % 64 == 0, "chunks");
@@ -1438,6 +1439,7 @@ __device__ __forceinline__ void lanes_pass(const LaneStream &ls, uint32_t s0, bo
   lane_ring_sync();
   uint32_t rel = r0 * kLaneChunkBits + in, k = (s0 + rel) >> 6, s = (s0 + rel) & 63u, tok = 0, px = 0;
   uint64_t A = sh.ring[k % kLaneRing][tid], B = sh.ring[(k + 1) % kLaneRing][tid], C = sh.ring[(k + 2) % kLaneRing][tid];
+  uint64_t held = 0;  // an even-numbered record waiting for its neighbour
   bool stopped = false;
 #pragma unroll 1
   for (uint32_t r = r0; r < kLaneRounds; r++) {
@@ -1453,7 +1455,12 @@ __device__ __forceinline__ void lanes_pass(const LaneStream &ls, uint32_t s0, bo
           if (!warm) { stopped = true; break; }
           hop = 1;  // this need not be a token start, try the next bit
         } else {
-          if (kRecord && tok < cap) rec[tok] = (uint64_t)val | ((uint64_t)cnt << 32) | ((uint64_t)(ref ? 1u : 0u) << 40);
+          if (kRecord && tok < cap) {
+            // two records to a 16-byte store (the parts of the record array start at multiples of 16 bytes, cap is even)
+            const uint64_t rcd = (uint64_t)val | ((uint64_t)cnt << 32) | ((uint64_t)(ref ? 1u : 0u) << 40);
+            if (tok & 1u) *reinterpret_cast<ulonglong2 *>(rec + tok - 1) = make_ulonglong2(held, rcd);
+            else held = rcd;
+          }
           tok++;
           px += cnt;
         }
@@ -1466,6 +1473,7 @@ __device__ __forceinline__ void lanes_pass(const LaneStream &ls, uint32_t s0, bo
     if (more) ls.store(r + 2, tid, regs, sh);
     lane_ring_sync();
   }
+  if (kRecord && run && (tok & 1u) && tok - 1 < cap) rec[tok - 1] = held;
   if (run) { out = stopped ? kParStop : rel - kLaneBits; ntok = tok; npx = px; }
 }
 
