@@ -254,6 +254,7 @@ struct DecAccel {
   bool driver_pixels = false;
   bool driver_multi = false;  // ... also those with several Huffman groups
   bool driver_cache = false;  // ... also those with a colour cache
+  bool stop_at_main = false;  // kEvPixels for the main image whatever it holds (a driver that only wants to know what comes)
   bool on = false;  // win, ring and g0 are set (tested instead of the pointers)
 };
 constexpr uint32_t kInlineCopyMax = 16;   // longer copies go to the driver (kEvCopy)
@@ -493,7 +494,8 @@ VP8L_HD uint32_t dec_step(DecState &st, const DecAccel &acc = DecAccel()) {
         break;
       }
       case kPhPixels: {
-        if (acc.driver_pixels && (st.ngroups == 1 || acc.driver_multi) && (st.cache_bits == 0 || acc.driver_cache) && st.fill == 0 && st.total < 0x7fffffffu) {
+        if (acc.driver_pixels && st.fill == 0 && st.total < 0x7fffffffu &&
+            (((st.ngroups == 1 || acc.driver_multi) && (st.cache_bits == 0 || acc.driver_cache)) || (acc.stop_at_main && st.dst == st.out))) {
           VP8L_SAVE_BR();
           return kEvPixels;
         }

@@ -1749,6 +1749,7 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
   __shared__ uint32_t s_ev;
   const uint32_t img = blockIdx.x, tid = threadIdx.x;
   const DecImage im = imgs[img];
+  if (res[img].pad2) return;  // k_decode_headers gave its verdict or handed the main image to the segment kernels
   DecAccel acc;
   acc.win = win;
   acc.win_bytes = kWgWindow;
@@ -1820,6 +1821,96 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
     r.need_groups = st.need_groups;
     r.nxf = st.nxf;
     r.standard = st.standard;
+    for (uint32_t k = 0; k < 4; k++) r.xf[k] = st.xf[k];
+  }
+}
+
+// Calls whose streams go to the segment kernels start with this one: a wave per stream reads the header and the tables (and
+// decodes the transforms' sub-images), and hands the main image over exactly as k_decode_entropy_wg would.  A workgroup of
+// 1024 threads per stream is one stream per CU, and parsing a header takes a lane about 0.75 ms: 512 streams took two
+// rounds of that, 3584 small ones fourteen; a wave per stream lets seven share a CU.  Streams it does not hand over
+// (small images, several Huffman groups, a colour cache) are left untouched for k_decode_entropy_wg, which skips the others.
+__global__ __launch_bounds__(64) void k_decode_headers(const DecImage *__restrict__ imgs, DecResult *__restrict__ res) {
+  __shared__ DecState st;
+  __shared__ GroupTables g0;
+  __shared__ union RingOrScratch {
+    uint32_t ring[kRingPixels];
+    DecTableScratch scratch;
+  } ros;
+  __shared__ uint32_t win[kStreamWindow / 4];
+  const uint32_t img = blockIdx.x, lane = threadIdx.x;
+  const DecImage im = imgs[img];
+  if (!im.par || (uint64_t)im.w * im.h < kParMinPixels) return;  // too small for the segment kernels whatever it holds
+  DecAccel acc;
+  acc.win = win;
+  acc.win_bytes = kStreamWindow;
+  acc.ring = ros.ring;
+  acc.ring_mask = kRingPixels - 1;
+  acc.g0 = &g0;
+  acc.driver_pixels = true;
+  acc.stop_at_main = true;
+  acc.on = true;
+  if (lane == 0) {
+    dec_init(st, im.data, im.len, im.out, im.aux, im.aux_cap, &g0, im.groups, im.group_cap, im.cache, &ros.scratch, im.sorted);
+    st.w = im.w;
+    st.h = im.h;
+  }
+  __syncthreads();
+  bool finished = false;  // a verdict (an error), or the main image handed over: k_decode_entropy_wg passes the stream by
+  for (;;) {
+    uint32_t ev = kEvDone;
+    if (lane == 0) ev = dec_step(st, acc);
+    ev = (uint32_t)__shfl((int)ev, 0, 64);
+    if (ev == kEvDone) { finished = st.status != kOk; break; }  // without an error the whole image was decoded here: cannot happen, the main image stops the loop
+    __syncthreads();
+    if (ev == kEvPixels) {
+      if (st.dst == st.out) {
+        if (st.total >= kParMinPixels && st.ngroups == 1 && st.cache_bits == 0) {
+          ParImage *par = im.par;
+          for (uint32_t i = lane; i < sizeof(GroupTables) / 4; i += 64)
+            reinterpret_cast<uint32_t *>(&par->tables)[i] = reinterpret_cast<const uint32_t *>(&g0)[i];
+          if (lane == 0) {
+            par->P0 = st.bytepos * 8 - st.cnt;
+            par->total = (uint32_t)st.total;
+            par->xsize = st.xsize | (st.standard << 31);
+            par->dst = st.dst;
+            par->active = 1;
+            par->fold_green = st.nxf && st.xf[st.nxf - 1].type == 2 ? 1u : 0u;  // see k_decode_entropy_wg
+            if (par->fold_green) st.nxf--;
+            st.status = kParPending;
+          }
+          __syncthreads();
+          finished = true;
+        }
+        break;
+      }
+      wave_decode_pixels((VP8L_LDS DecState *)&st, (const VP8L_LDS GroupTables *)&g0, (VP8L_LDS uint32_t *)ros.ring,
+                         (VP8L_LDS uint32_t *)win, im, lane);
+    } else if (ev == kEvRefill) {
+      const uint64_t lo = st.bytepos;
+      window_load(win, im, lo, lane);
+      if (lane == 0) { st.win_lo = lo; st.win_hi = lo + kStreamWindow; st.win_final = lo + kStreamWindow >= im.len; }
+    } else {
+      __threadfence_block();
+      uint32_t *dst = st.dst;
+      const uint64_t pos = st.copy_pos;
+      const uint32_t dist = st.copy_dist, len = st.copy_len;
+      for (uint32_t i = lane; i < len; i += 64) {
+        const uint32_t v = dst[pos - dist + (dist >= len ? i : i % dist)];
+        dst[pos + i] = v;
+        if (i + kRingPixels >= len) ros.ring[(uint32_t)(pos + i) & (kRingPixels - 1)] = v;
+      }
+      __threadfence_block();
+    }
+    __syncthreads();
+  }
+  if (lane == 0 && finished) {
+    DecResult &r = res[img];
+    r.status = st.status;
+    r.need_groups = st.need_groups;
+    r.nxf = st.nxf;
+    r.standard = st.standard;
+    r.pad2 = 1;  // done with: the workgroup form passes it by
     for (uint32_t k = 0; k < 4; k++) r.xf[k] = st.xf[k];
   }
 }
@@ -2295,7 +2386,10 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
   // A workgroup per stream decodes one stream several times faster than a wave per stream; the waves only win
   // with thousands of small streams of noisy content, so they are an option, not the default.
   if (d->threads_per_stream == 64) hipLaunchKernelGGL(k_decode_entropy, dim3(m), dim3(64), 0, s, dimgs, dres);
-  else hipLaunchKernelGGL(k_decode_entropy_wg, dim3(m), dim3(kWgThreads), 0, s, dimgs, dres);
+  else {
+    if (whole_device) hipLaunchKernelGGL(k_decode_headers, dim3(m), dim3(64), 0, s, dimgs, dres);
+    hipLaunchKernelGGL(k_decode_entropy_wg, dim3(m), dim3(kWgThreads), 0, s, dimgs, dres);
+  }
   if (whole_device) {
     // streams whose main image k_decode_entropy_wg left to the segment kernels (the others are finished: these kernels pass them by)
     const uint32_t *segf = d->d_segfirst.as<uint32_t>();
