@@ -1089,13 +1089,20 @@ __device__ __forceinline__ uint32_t flag_at(const uint32_t *__restrict__ flags, 
 // symbols of strictly sequential work (sorted-merge Huffman with the reference's tie rule, RLE,
 // nested code): lane 0 of one wave runs the host/device core out of LDS.
 // =============================================================================================
+// A code's description takes at most 1 + 6 + 68 * 6 + 1 bits of preamble and, per run-length item (at most 280), a
+// code-length symbol and up to 7 extra bits; the code-length code is built from at most 280 counts, so none of its codes is
+// longer than 11 bits (a code of depth d needs Fibonacci(d + 2) counts): 5456 bits at most.
+constexpr uint32_t kDescBufWords = 256;
+static_assert(kDescBufWords * 32 >= 1 + 6 + 68 * 6 + 1 + 280 * (11 + 7), "a description fits its buffer");
 struct HeaderShared {
-  SubImageScratch sub;
-  CodeTables tables;
-  uint32_t histo[kNumCodes * kCodeStride];
+  SubImageScratch sub;     // its histogram and tables serve the sub-images first, then the main image
   uint32_t palette[kMaxPalette];
-  HuffScratch huff[3];  // waves 1..3; wave 0 uses sub.desc.huff
+  DescScratch desc[3];     // waves 1..3; wave 0 uses sub.desc
   int rc[kNumCodes];
+  // the five descriptions of the main image's codes, written side by side and then appended to the stream
+  uint32_t dbuf[kNumCodes][kDescBufWords];
+  uint32_t dbits[kNumCodes];
+  int drc[kNumCodes];
 };
 
 // The used symbols' weights in symbol order and their ids sorted by (weight, id), by the whole wave
@@ -1128,8 +1135,12 @@ __device__ __forceinline__ int wave_prepare_leaves(const uint32_t *h, int n, Scr
 // by side (wave 0 then adds the distance code); the sort of each is done by its wave, the joining of the tree
 // by the wave's first lane.  rc[c] < 0: that code failed (TooBigCodeLength).  Ends with a barrier.
 // standard: codes of at most 15 bits (the histogram is then changed in place, huffman_lengths_limited).
-__device__ __forceinline__ void build_codes_4waves(uint32_t *histo5, CodeTables &t, int *rc, HuffScratch &hs, uint32_t wave,
-                                                   uint32_t lane, bool standard) {
+// describe: a wave's first lane also writes the description of each code it has built (vp8l.h:536-540) into the code's
+// own bit buffer dbuf[c] (dbits[c] bits, drc[c] = status), so the five descriptions are written side by side.
+__device__ __forceinline__ void build_codes_4waves(uint32_t *histo5, CodeTables &t, int *rc, DescScratch &ds, uint32_t wave,
+                                                   uint32_t lane, bool standard, uint32_t (*dbuf)[kDescBufWords] = nullptr,
+                                                   uint32_t *dbits = nullptr, int *drc = nullptr) {
+  HuffScratch &hs = ds.huff;
   for (uint32_t c = wave; c < (uint32_t)kNumCodes; c += 4) {
     const int nsym = alphabet_size((int)c);
     uint32_t *h = histo5 + c * kCodeStride;
@@ -1141,6 +1152,13 @@ __device__ __forceinline__ void build_codes_4waves(uint32_t *histo5, CodeTables 
       if (u >= 0) {
         t.used[c] = (uint32_t)u;
         canonical_reversed_codes(len, nsym, t.code + c * kCodeStride);
+      }
+      if (dbuf) {
+        BitSink b;
+        b.init(dbuf[c]);
+        drc[c] = u < 0 ? u : write_code_desc(b, len, nsym, ds, standard);  // the code is built: its scratch is free again
+        b.flush();
+        dbits[c] = (uint32_t)b.bits();
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1161,7 +1179,6 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
   const EncImage im = imgs[img];
   const uint32_t ncolors = st[img].ncolors;
   const uint32_t *g = histo + (size_t)img * kNumCodes * kCodeStride;
-  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) sh.histo[i] = g[i];
   for (uint32_t i = tid; i < kMaxPalette; i += 256) sh.palette[i] = st[img].palette[i];
   if (tid == 0) {
     bw.init(reinterpret_cast<uint32_t *>(out + im.out_off));
@@ -1169,7 +1186,7 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
     s_rc = 0;
   }
   __syncthreads();
-  HuffScratch &hs = wave == 0 ? sh.sub.desc.huff : sh.huff[wave - 1];
+  DescScratch &ds = wave == 0 ? sh.sub.desc : sh.desc[wave - 1];
   // Sub-images go in front of the main image's codes: the palette as ncolors x 1 (vp8l.h:455-457), or the predictor
   // modes as pred_tx x pred_ty and then the cross-colour elements as cross_tx x cross_ty (read by ReadTransform
   // vp8l.h:111-121), in the order the transforms were applied.
@@ -1219,7 +1236,7 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
     __syncthreads();
     if (tid == 0) small_histogram(d, np, sub_xsize, sh.sub);
     __syncthreads();
-    build_codes_4waves(sh.sub.histo, sh.sub.tables, sh.rc, hs, wave, lane, standard != 0);
+    build_codes_4waves(sh.sub.histo, sh.sub.tables, sh.rc, ds, wave, lane, standard != 0);
     if (tid == 0 && s_rc == 0) {
       bw.put(0, 1);  // no colour cache
       int rc = 0;
@@ -1249,18 +1266,26 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
     }
     return;
   }
-  build_codes_4waves(sh.histo, sh.tables, sh.rc, hs, wave, lane, standard != 0);
+  // the main image: its histogram into the place the sub-images' had (the loop above ends with a barrier)
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) sh.sub.histo[i] = g[i];
+  __syncthreads();
+  build_codes_4waves(sh.sub.histo, sh.sub.tables, sh.rc, ds, wave, lane, standard != 0, sh.dbuf, sh.dbits, sh.drc);
   if (tid == 0) {
     int rc = s_rc;
     if (rc == 0) write_stream_tail(bw);
-    for (int c = 0; c < kNumCodes && rc == 0; c++)  // vp8l.h:536-540
-      rc = sh.rc[c] < 0 ? sh.rc[c] : write_code_desc(bw, sh.tables.len + c * kCodeStride, alphabet_size(c), sh.sub.desc, standard != 0);
+    for (int c = 0; c < kNumCodes && rc == 0; c++) {  // vp8l.h:536-540
+      rc = sh.drc[c];
+      const uint32_t *w = sh.dbuf[c];
+      uint32_t left = rc == 0 ? sh.dbits[c] : 0u;
+      for (; left >= 32; left -= 32) bw.put(*w++, 32);
+      if (left) bw.put(*w & ((1u << left) - 1u), left);
+    }
     bw.flush();
     st[img].hdr_bits = (uint32_t)bw.bits();
     st[img].status = rc;
   }
   __syncthreads();
-  const uint32_t *src = reinterpret_cast<const uint32_t *>(&sh.tables);
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(&sh.sub.tables);
   uint32_t *dst = reinterpret_cast<uint32_t *>(&tables[img]);
   for (uint32_t i = tid; i < sizeof(CodeTables) / 4; i += 256) dst[i] = src[i];
 }
