@@ -320,3 +320,39 @@ def test_lane_scouts_built_with_512_threads():
                        env=dict(os.environ, VP8L_AMD_LIB=lib), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+EXT_KINDS = [
+    dict(use_subtract_green=1), dict(predictor_bits=2), dict(color_bits=3), dict(predictor_bits=3, color_bits=2, use_subtract_green=1, transform_order=1),
+    dict(cache_bits=4), dict(cache_bits=11, use_subtract_green=1), dict(meta_bits=2, meta_groups=3),
+    dict(meta_bits=3, meta_groups=7, cache_bits=6, predictor_bits=3, use_subtract_green=1), dict(use_palette=1, cache_bits=3),
+    dict(use_palette=1, meta_bits=2, meta_groups=2),
+]
+
+
+def test_thousands_of_small_streams_in_one_call():
+    # a call with at least 1024 small streams is decoded by a wave per stream instead of a workgroup per stream: every kind
+    # of stream, and damaged ones, in one such call
+    rng = np.random.default_rng(99)
+    streams = []
+    for prm in EXT_KINDS:
+        for (w, h) in ((7, 5), (33, 18), (64, 64)):
+            for mode in (3, 4, 5):
+                rc, s = O.encode_ext(O.gen_image(mode, w, h, 11, 200), w, h, **prm)
+                assert rc == 0
+                streams.append(s)
+    for (w, h) in ((1, 1), (40, 30), (255, 200)):
+        for mode in (3, 4, 5):
+            streams.append(O.encode(O.gen_image(mode, w, h, 3, 60), w, h)[1])
+    base = list(streams)
+    while len(streams) < 1100:
+        b = bytearray(base[int(rng.integers(0, len(base)))])
+        if len(b) > 12 and rng.random() < 0.5:
+            b[int(rng.integers(9, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        streams.append(bytes(b))
+    res = decode_with(0, streams, whole_device=0)   # one call through the device-memory entry point
+    for k, (s, (st, arr)) in enumerate(zip(streams, res)):
+        rc0, ref, w0, h0 = O.decode(s)
+        assert st == rc0, (k, st, rc0)
+        if rc0 == 0:
+            assert np.array_equal(arr, ref), k

@@ -1830,7 +1830,10 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
 // 1024 threads per stream is one stream per CU, and parsing a header takes a lane about 0.75 ms: 512 streams took two
 // rounds of that, 3584 small ones fourteen; a wave per stream lets seven share a CU.  Streams it does not hand over
 // (small images, several Huffman groups, a colour cache) are left untouched for k_decode_entropy_wg, which skips the others.
-__global__ __launch_bounds__(64) void k_decode_headers(const DecImage *__restrict__ imgs, DecResult *__restrict__ res) {
+// small_too: images too small for the segment kernels are decoded here to the end, as k_decode_entropy would (a call with
+// thousands of small streams: seven of them share a CU here, one at a time has it in the workgroup form; 4096 streams of
+// 64x64 pixels 16.8 -> 4.5 ms).
+__global__ __launch_bounds__(64) void k_decode_headers(const DecImage *__restrict__ imgs, DecResult *__restrict__ res, uint32_t small_too) {
   __shared__ DecState st;
   __shared__ GroupTables g0;
   __shared__ union RingOrScratch {
@@ -1840,7 +1843,8 @@ __global__ __launch_bounds__(64) void k_decode_headers(const DecImage *__restric
   __shared__ uint32_t win[kStreamWindow / 4];
   const uint32_t img = blockIdx.x, lane = threadIdx.x;
   const DecImage im = imgs[img];
-  if (!im.par || (uint64_t)im.w * im.h < kParMinPixels) return;  // too small for the segment kernels whatever it holds
+  const bool small = (uint64_t)im.w * im.h < kParMinPixels;  // too small for the segment kernels whatever it holds
+  if (small ? !small_too : !im.par) return;
   DecAccel acc;
   acc.win = win;
   acc.win_bytes = kStreamWindow;
@@ -1848,7 +1852,7 @@ __global__ __launch_bounds__(64) void k_decode_headers(const DecImage *__restric
   acc.ring_mask = kRingPixels - 1;
   acc.g0 = &g0;
   acc.driver_pixels = true;
-  acc.stop_at_main = true;
+  acc.stop_at_main = !small;
   acc.on = true;
   if (lane == 0) {
     dec_init(st, im.data, im.len, im.out, im.aux, im.aux_cap, &g0, im.groups, im.group_cap, im.cache, &ros.scratch, im.sorted);
@@ -1861,10 +1865,10 @@ __global__ __launch_bounds__(64) void k_decode_headers(const DecImage *__restric
     uint32_t ev = kEvDone;
     if (lane == 0) ev = dec_step(st, acc);
     ev = (uint32_t)__shfl((int)ev, 0, 64);
-    if (ev == kEvDone) { finished = st.status != kOk; break; }  // without an error the whole image was decoded here: cannot happen, the main image stops the loop
+    if (ev == kEvDone) { finished = small || st.status != kOk; break; }  // a small image is done; a large one only gets here with an error (its main image stops the loop)
     __syncthreads();
     if (ev == kEvPixels) {
-      if (st.dst == st.out) {
+      if (!small && st.dst == st.out) {
         if (st.total >= kParMinPixels && st.ngroups == 1 && st.cache_bits == 0) {
           ParImage *par = im.par;
           for (uint32_t i = lane; i < sizeof(GroupTables) / 4; i += 64)
@@ -2336,6 +2340,10 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
   }
   sb_first[m] = (uint32_t)sb_total;
   seg_first[m] = (uint32_t)seg_total;
+  // Thousands of small streams: a wave per stream gets through them faster than a workgroup per stream (see k_decode_headers).
+  uint32_t small_streams = 0;
+  for (uint32_t k = 0; k < m; k++) small_streams += (uint64_t)imgs[k].w * imgs[k].h < kParMinPixels ? 1u : 0u;
+  const bool many_small = d->threads_per_stream == 0 && small_streams >= 1024;
   uint32_t max_bands = 1;
   for (uint32_t k = 0; k < m; k++) max_bands = std::max(max_bands, (height[idx[k]] + kBandRows - 1) / kBandRows);
   const bool ok = d->d_imgs.reserve(m * sizeof(DecImage)) && d->d_res.reserve(m * sizeof(DecResult)) &&
@@ -2387,7 +2395,7 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
   // with thousands of small streams of noisy content, so they are an option, not the default.
   if (d->threads_per_stream == 64) hipLaunchKernelGGL(k_decode_entropy, dim3(m), dim3(64), 0, s, dimgs, dres);
   else {
-    if (whole_device) hipLaunchKernelGGL(k_decode_headers, dim3(m), dim3(64), 0, s, dimgs, dres);
+    if (whole_device || many_small) hipLaunchKernelGGL(k_decode_headers, dim3(m), dim3(64), 0, s, dimgs, dres, many_small ? 1u : 0u);
     hipLaunchKernelGGL(k_decode_entropy_wg, dim3(m), dim3(kWgThreads), 0, s, dimgs, dres);
   }
   if (whole_device) {
