@@ -102,10 +102,15 @@ __global__ __launch_bounds__(256) void k_palette_scan(const EncImage *__restrict
   __syncthreads();
   for (uint32_t it = 0; it < kSuper / 256; it++) {
     const uint64_t i = base + (uint64_t)it * 256 + tid;
-    if (i < npx) {
-      const int r = set_insert(set, im.argb[i]);
-      if (r == 1) atomicAdd(&s_count, 1u);
-      if (r == 2) s_over = 1;
+    {
+      // a pixel equal to the one before it (the lane below) adds nothing: flat areas cost one insertion per run and wave
+      const uint32_t v = i < npx ? im.argb[i] : 0u;
+      const uint32_t left = (uint32_t)__shfl_up((int)v, 1, 64);
+      if (i < npx && ((tid & 63) == 0 || v != left)) {
+        const int r = set_insert(set, v);
+        if (r == 1) atomicAdd(&s_count, 1u);
+        if (r == 2) s_over = 1;
+      }
     }
     if (tid == 0 && (it & 7) == 7 &&
         __hip_atomic_load(&st[img].pal_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
