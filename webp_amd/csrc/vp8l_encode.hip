@@ -631,6 +631,13 @@ __device__ unsigned long long g_sp_phase[8];
 #define VP8L_PHASE_MARK(k) do {} while (0)
 #endif
 
+// Orders a wave's LDS writes before the reads other lanes of the same wave make afterwards
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 constexpr uint32_t kSpThreads = 512;
 constexpr uint32_t kSpWaves = kSpThreads / 64;
 constexpr uint32_t kSpTile = 2048;                   // positions per workgroup
@@ -649,6 +656,11 @@ static_assert(kSpSources <= (1u << kSpPosBits) && kSpSources % kSpThreads == 0 &
 static_assert(kSpThreads * kSpSeg >= kSpSources + kMaxLen, "run-length pass covers the window");
 static_assert(kSpBuckets == 8 * kSpThreads, "8 buckets per thread in the scan");
 static_assert(kSpTile == kLzTile, "one flag per tile");
+constexpr uint32_t kSpQueue = 64;                           // candidates a wave collects before it scores them
+constexpr uint32_t kSpWaveAux = 2 * 64 + kSpQueue;          // words per wave: 128 keys + the queue
+constexpr uint32_t kSpAuxWords = (kSpSources + kMaxLen) / 2;
+static_assert(kSpWaves * kSpWaveAux <= kSpAuxWords, "keys and queues fit where the run lengths would be");
+static_assert(kSpTile / kSpThreads == 4, "positions of a thread are handled as two pairs");
 
 __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                      const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
@@ -656,7 +668,11 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
                                                      uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile, uint32_t tune_per_value,
                                                      uint32_t tune_budget, uint32_t tune_max_bucket) {
   __shared__ __attribute__((aligned(16))) uint32_t px[kSpSources + kMaxLen + 4];
-  __shared__ uint16_t runlen[kSpSources + kMaxLen];  // pixels equal to this one from here on (within the window)
+  // Tiles with runs: runlen[i] = pixels equal to pixel i from there on (within the window), 16 bits each.  Tiles without
+  // runs use the same memory per wave: the best match so far of the 128 positions the wave is working on and a queue of
+  // 64 candidates (see the search below).
+  __shared__ uint32_t aux[kSpAuxWords];
+  uint16_t *runlen = reinterpret_cast<uint16_t *>(aux);
   // counts, then insert positions; after the scatter cursor[h] = end of bucket h.  16 bits each (at most kSpSources), two to
   // a word that the LDS atomics add to: 8 KB less LDS lets a fourth workgroup onto the CU
   __shared__ uint32_t cursor2[kSpBuckets / 2];
@@ -818,12 +834,120 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   }
   __syncthreads();
   VP8L_PHASE_MARK(3);  // scan of the counts and scatter into the buckets
-  // every thread: positions a+tid, a+tid+512, ...
+  // ---- tiles without runs: collect, then score.  A wave walks the buckets of 64 positions at a time and only *collects* the sources that
+  // hold the position's value within its window (most walks find none, and a wave that scored them where it found
+  // them would run the whole scoring code for one or two lanes).  Candidates go into the wave's queue; whenever 64 are
+  // waiting, and at the end of two rounds of positions, every lane scores one: it extends the match and raises the
+  // position's key length << 11 | distance with an LDS maximum - the longest match wins, among equals the farthest
+  // (lz77.h:68), which is the order of the keys, so candidates can be scored in any order.  Queue and keys (`mem`: 128
+  // keys, 64 queue entries) belong to the wave alone: no workgroup barrier in here, and results are stored as soon as a
+  // pair of rounds is done (a tile that gives up later is redone as a whole by the exhaustive kernel).
+  auto collect_and_score = [&](uint32_t *keys) {
+    uint32_t *queue = keys + 128;
+    uint32_t spent = 0;
+#pragma unroll 1
+    for (uint32_t pair = 0; pair < 2; pair++) {
+      keys[lane] = 0;
+      keys[64 + lane] = 0;
+      const uint32_t ip0 = a - lo + pair * (2 * kSpThreads) + wave * 64;  // window index of lane 0's position in round 0
+      uint32_t qn = 0;                                                       // candidates waiting (the same in every lane)
+      auto score = [&](uint32_t n) {
+        wave_sync_lds();
+        if (lane < n) {
+          const uint32_t e = queue[lane];
+          const uint32_t s = e & ((1u << kSpPosBits) - 1), slot = e >> kSpPosBits;  // slot = round * 64 + owner's lane
+          const uint32_t ip = ip0 + (slot >> 6) * kSpThreads + (slot & 63u);
+          const uint32_t left = M - (lo + ip), rem = left < kMaxLen ? left : kMaxLen;
+          const uint32_t cur = keys[slot];  // what it must beat (others may be raising it meanwhile)
+          uint32_t key = cur;
+          // scores the source at index q (same value as the position, among the 1024 before it)
+          auto candidate = [&](uint32_t q) {
+            const uint32_t d = ip - q;
+            const uint32_t maxl = d < rem ? d : rem;  // no overlap with the source, at most 128, inside the image
+            // what it must reach to replace the best so far: longer, or as long and farther (lz77.h:68)
+            const uint32_t need = (key >> 11) + (d > (key & 2047u) ? 0u : 1u);
+            if (maxl < need) return;
+            if (need > 1 && px[q + need - 1] != px[ip + need - 1]) return;
+            uint32_t l = 1;
+            while (l < maxl && px[q + l] == px[ip + l]) l++;
+            spent += l;
+            if (l >= need) key = (l << 11) | d;
+          };
+          candidate(s);
+          if (key > cur) atomicMax(&keys[slot], key);
+        }
+        wave_sync_lds();
+      };
+      // the whole wave offers: lanes with `cand` put source t of their position of round kk into the queue; a lane
+      // whose candidate found no room gets false and offers it again (the queue is scored and emptied when it is full)
+      auto offer = [&](bool cand, uint32_t t, uint32_t kk) {
+        const uint64_t cm = __ballot(cand);
+        if (!cm) return true;
+        const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+        const bool fits = at < kSpQueue;
+        if (cand && fits) queue[at] = ((kk * 64 + lane) << kSpPosBits) | t;
+        qn += (uint32_t)__popcll(cm);
+        if (qn >= kSpQueue) {
+          score(kSpQueue);
+          qn = 0;
+        }
+        return !cand || fits;
+      };
+#pragma unroll 1
+      for (uint32_t kk = 0; kk < 2; kk++) {
+        const uint32_t ip = ip0 + kk * kSpThreads + lane;
+        uint32_t i = 0, end = 0, tag = 0, span = 0;
+        if (lo + ip < b) {
+          const uint32_t x = px[ip], mxd = x * kSpMul, h = mxd >> (32 - kSpPosBits);
+          tag = mxd << kSpTagShift;
+          end = cursor[h];
+          i = h ? cursor[h - 1] : 0u;
+          span = ip < kWindow ? ip : kWindow;  // sources ip - span .. ip - 1
+        }
+        for (;;) {
+          const bool live = i < end;
+          if (!__ballot(live)) break;
+          // an entry of the same value has the tag's bits, so t is its index; any other t is at least 4096 and fails
+          // the one comparison that also keeps the index among the `span` before the position
+          uint32_t t = 0;
+          bool cand = false;
+          if (live) {
+            t = items[i] ^ tag;
+            cand = ip - 1 - t < span;
+          }
+          const bool taken = offer(cand, t, kk);  // by every lane: the queue is the wave's
+          if (live && taken) { i++; spent++; }
+        }
+      }
+      if (qn) score(qn);
+#pragma unroll
+      for (uint32_t kk = 0; kk < 2; kk++) {
+        const uint32_t p = lo + ip0 + kk * kSpThreads + lane;
+        if (p < b) {
+          uint32_t key = keys[kk * 64 + lane];
+          if (p == M - 1) key = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
+          const uint32_t o = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_code_of(xsize, xinv, key & 2047u) << 19)) : 0u;
+          match[pos0 + p] = o;
+          adv[pos0 + p] = (uint8_t)((o & 0xff) ? (o & 0xff) : 1u);
+        }
+      }
+      if (__ballot(spent > tune_budget)) {  // too much work for this form: the exhaustive kernel redoes the tile
+        if (lane == 0) dense_tile[(pos0 + a) / kLzTile] = 1;
+        return;
+      }
+    }
+  };
+  if (plain) {
+    collect_and_score(aux + wave * kSpWaveAux);  // keys and queues where the run lengths of other tiles are
+    return;
+  }
+  // ---- tiles with runs: candidates are scored where they are found.  (Collecting them first, as above, made these
+  // tiles slower, 4.4 -> 5.0 ms per 64 graphics images of 3840x2160: flat areas give a position many candidates, and
+  // scored one after the other nearly all of them fail the first comparison against the best so far.)
+  // Every thread: positions a+tid, a+tid+512, ...
   uint32_t out[kSpTile / kSpThreads];
   uint32_t spent = 0;
   bool over = false;
-  auto search = [&](auto plain_c) {
-  constexpr bool kPlain = decltype(plain_c)::value;
 #pragma unroll 1
   for (uint32_t k = 0; k < kSpTile / kSpThreads; k++) {
     const uint32_t p = a + k * kSpThreads + tid;
@@ -833,7 +957,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
       const uint32_t mxd = x * kSpMul, h = mxd >> (32 - kSpPosBits), tag = mxd << kSpTagShift;
       const uint32_t end = cursor[h], beg = h ? cursor[h - 1] : 0u;
       const uint32_t rem = M - p < kMaxLen ? M - p : kMaxLen;
-      const uint32_t F = kPlain ? 1u : runlen[ip];         // >= 128 means "at least 128"
+      const uint32_t F = runlen[ip];                          // >= 128 means "at least 128"
       const uint32_t wlo = ip > kWindow ? ip - kWindow : 0u;  // farthest source of p
       // scores the source at index q (same value as p, wlo <= q < ip)
       auto candidate = [&](uint32_t q) {
@@ -843,30 +967,22 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
         const uint32_t need = (key >> 11) + (d > (key & 2047u) ? 0u : 1u);
         if (maxl < need) return;
         if (need > 1 && px[q + need - 1] != px[ip + need - 1]) return;
-        uint32_t l;
-        if (kPlain) {
-          l = 1;
-          while (l < maxl && px[q + l] == px[ip + l]) l++;
-          spent += l;
-        } else {
-          l = 0;
-          do {  // both sides advance by whole runs
-            const uint32_t rq = runlen[q + l], rp = runlen[ip + l];
-            l += rq < rp ? rq : rp;
-            spent++;
-          } while (l < maxl && px[q + l] == px[ip + l]);
-          l = l < maxl ? l : maxl;
-        }
+        uint32_t l = 0;
+        do {  // both sides advance by whole runs
+          const uint32_t rq = runlen[q + l], rp = runlen[ip + l];
+          l += rq < rp ? rq : rp;
+          spent++;
+        } while (l < maxl && px[q + l] == px[ip + l]);
+        l = l < maxl ? l : maxl;
         if (l >= need) key = (l << 11) | d;
       };
       // a source run and, when it ends before p and is longer than p's run, the source aligned with the end of p's run
       auto source_run = [&](uint32_t s) {
         candidate(s);
-        if (kPlain) return;
         const uint32_t r = runlen[s];
         if (F < kMaxLen && r > F && s + r <= ip) candidate(s + r - F);
       };
-      if (!kPlain && wlo > 0 && px[wlo] == x && px[wlo - 1] == x) source_run(wlo);  // the run that the window start cuts
+      if (wlo > 0 && px[wlo] == x && px[wlo - 1] == x) source_run(wlo);  // the run that the window start cuts
       for (uint32_t i = beg; i < end; i++) {
         const uint32_t it = items[i];
         const uint32_t s = it & ((1u << kSpPosBits) - 1);
@@ -879,8 +995,6 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
     }
     out[k] = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_code_of(xsize, xinv, key & 2047u) << 19)) : 0u;
   }
-  };
-  if (plain) search(std::true_type{}); else search(std::false_type{});
   VP8L_PHASE_MARK(4);  // the search (first wave's share; the workgroup ends with its slowest wave)
   if (over) s_abort = 1;
   __syncthreads();
