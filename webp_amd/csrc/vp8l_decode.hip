@@ -1698,26 +1698,39 @@ __global__ __launch_bounds__(256) void k_par_jump(const DecImage *__restrict__ i
     uint32_t *srcg = par->srcg, *dst = par->dst;
     const uint32_t total = par->total;
     bool open = false;
-    for (uint32_t k = 0; k < kUnit / 256; k++) {
-      const uint64_t p = p0 + k * 256 + threadIdx.x;
-      if (p < total) {
-        const uint32_t v = srcg[p];
-        if (!(v & kFinalBit)) {
-          // the source's own source, up to three steps on; read while its owner replaces it, it is the old or the new
-          // one: both lead to the same literal
-          uint32_t t = __hip_atomic_load(&srcg[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // A thread's pixels of the unit in groups of kJumpBatch: their chains are followed side by side (a hop is a
+    // dependent read of a microsecond; one pixel after the other left a wave with one read in flight per lane).
+    constexpr uint32_t kJumpBatch = 4;
+    static_assert((kUnit / 256) % kJumpBatch == 0, "groups of pixels per thread");
+    for (uint32_t k0 = 0; k0 < kUnit / 256; k0 += kJumpBatch) {
+      uint32_t t[kJumpBatch];
+      bool mine[kJumpBatch];  // a pixel whose chain is still open
+#pragma unroll
+      for (uint32_t j = 0; j < kJumpBatch; j++) {
+        const uint64_t p = p0 + (k0 + j) * 256 + threadIdx.x;
+        t[j] = p < total ? srcg[p] : kFinalBit;
+        mine[j] = !(t[j] & kFinalBit);
+      }
+      // the source's own source, several steps on; read while its owner replaces it, it is the old or the new one: both
+      // lead to the same literal
 #ifndef VP8L_JUMP_HOPS
 #define VP8L_JUMP_HOPS 5
 #endif
 #pragma unroll
-          for (int hop = 1; hop < VP8L_JUMP_HOPS; hop++)
-            if (!(t & kFinalBit)) t = __hip_atomic_load(&srcg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&srcg[p], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          // a chain that has reached its literal (whose pixel the kernels before this one wrote) gives the pixel its value
-          // here, once: the position is final from now on and no pass looks at it again
-          if (t & kFinalBit) dst[p] = dst[t & ~kFinalBit];
-          else open = true;
-        }
+      for (int hop = 0; hop < VP8L_JUMP_HOPS; hop++) {
+#pragma unroll
+        for (uint32_t j = 0; j < kJumpBatch; j++)
+          if (!(t[j] & kFinalBit)) t[j] = __hip_atomic_load(&srcg[t[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < kJumpBatch; j++) {
+        if (!mine[j]) continue;
+        const uint64_t p = p0 + (k0 + j) * 256 + threadIdx.x;
+        __hip_atomic_store(&srcg[p], t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // a chain that has reached its literal (whose pixel the kernels before this one wrote) gives the pixel its value
+        // here, once: the position is final from now on and no pass looks at it again
+        if (t[j] & kFinalBit) dst[p] = dst[t[j] & ~kFinalBit];
+        else open = true;
       }
     }
     if (__syncthreads_or(open) && threadIdx.x == 0) { par->changed[pass] = 1; any_open[pass] = 1; }
