@@ -1606,8 +1606,10 @@ __global__ __launch_bounds__(256) void k_par_verify(const DecImage *__restrict__
 // 256 threads: eight workgroups per CU, so that the chains of dependent loads each starts with (image, workspace, segment)
 // overlap; a workgroup of 1024 threads per segment left two per CU (5.9 ms per 1080p batch).
 constexpr uint32_t kPlaceThreads = 256;
+constexpr uint32_t kPlaceTokens = 2;  // tokens per thread and round (1: 4.39 ms per 1080p batch, 2: 4.19, 4: 4.51)
 __global__ __launch_bounds__(kPlaceThreads) void k_par_place(const DecImage *__restrict__ imgs, const uint32_t *__restrict__ segfirst, uint32_t n) {
-  __shared__ uint32_t wsum[kPlaceThreads / 64];
+  __shared__ uint32_t wsum[kPlaceTokens * (kPlaceThreads / 64)];
+  static_assert(kPlaceTokens * (kPlaceThreads / 64) <= 64, "one wave scans the waves' sums");
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t img = find_image(segfirst, n, blockIdx.x), seg = blockIdx.x - segfirst[img];
   ParImage *par = imgs[img].par;
@@ -1640,41 +1642,60 @@ __global__ __launch_bounds__(kPlaceThreads) void k_par_place(const DecImage *__r
     }
     return rec[at];
   };
-  uint64_t rc_next = record(tid);
-  for (uint32_t t0 = 0; t0 < ntok && fill < total; t0 += kPlaceThreads) {
-    const uint64_t rc = rc_next;
-    rc_next = record(t0 + kPlaceThreads + tid);  // on its way while this round's tokens are placed
-    const uint32_t val = (uint32_t)rc, cnt = (uint32_t)(rc >> 32) & 0xffu;
-    const bool ref = (rc >> 40) & 1ull;
-    const uint32_t incl = wave_incl_scan_u32(cnt, (int)lane);
-    __syncthreads();
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    const uint32_t wsums = wave_incl_scan_u32(lane < kPlaceThreads / 64 ? wsum[lane] : 0u, (int)lane);
-    const uint32_t before = wave ? lane_read(wsums, wave - 1) : 0u, all = lane_read(wsums, kPlaceThreads / 64 - 1);
-    const uint32_t pos = fill + before + incl - cnt;
-    bool expand = false;
-    if (cnt && pos < total) {
-      if (pos + cnt > total) bad = true;        // a reference that runs past the end of the image
-      else if (!ref) { dst[pos] = fold_green ? add_green(val) : val; srcg[pos] = pos | kFinalBit; }
-      else if (val > pos) bad = true;           // a reference before the start of the image
-      else expand = true;
+  // A round places kPlaceTokens tokens per thread (token t0 + j * 256 + tid for j = 0 ...): a round costs two barriers and
+  // the latency of a scan whatever it places.
+  uint64_t rc_next[kPlaceTokens];
+#pragma unroll
+  for (uint32_t j = 0; j < kPlaceTokens; j++) rc_next[j] = record(j * kPlaceThreads + tid);
+  for (uint32_t t0 = 0; t0 < ntok && fill < total; t0 += kPlaceThreads * kPlaceTokens) {
+    uint32_t val[kPlaceTokens], cnt[kPlaceTokens], incl[kPlaceTokens];
+    bool ref[kPlaceTokens];
+#pragma unroll
+    for (uint32_t j = 0; j < kPlaceTokens; j++) {
+      const uint64_t rc = rc_next[j];
+      rc_next[j] = record(t0 + (kPlaceTokens + j) * kPlaceThreads + tid);  // on its way while this round's tokens are placed
+      val[j] = (uint32_t)rc;
+      cnt[j] = (uint32_t)(rc >> 32) & 0xffu;
+      ref[j] = (rc >> 40) & 1ull;
+      incl[j] = wave_incl_scan_u32(cnt[j], (int)lane);
     }
-    if (expand && cnt <= kWgOwnCopy) {
-      if (val >= cnt) {
-        for (uint32_t e = 0; e < cnt; e++) srcg[pos + e] = pos - val + e;
-      } else {
-        for (uint32_t e = 0; e < cnt; e++) srcg[pos + e] = pos - val + e % val;
+    __syncthreads();
+    if (lane == 63) {
+#pragma unroll
+      for (uint32_t j = 0; j < kPlaceTokens; j++) wsum[j * (kPlaceThreads / 64) + wave] = incl[j];
+    }
+    __syncthreads();
+    constexpr uint32_t kSums = kPlaceTokens * (kPlaceThreads / 64);  // in token order: j-major, then the wave
+    const uint32_t wsums = wave_incl_scan_u32(lane < kSums ? wsum[lane] : 0u, (int)lane);
+    const uint32_t all = lane_read(wsums, kSums - 1);
+#pragma unroll
+    for (uint32_t j = 0; j < kPlaceTokens; j++) {
+      const uint32_t idx = j * (kPlaceThreads / 64) + wave;
+      const uint32_t before = idx ? lane_read(wsums, idx - 1) : 0u;
+      const uint32_t pos = fill + before + incl[j] - cnt[j];
+      bool expand = false;
+      if (cnt[j] && pos < total) {
+        if (pos + cnt[j] > total) bad = true;        // a reference that runs past the end of the image
+        else if (!ref[j]) { dst[pos] = fold_green ? add_green(val[j]) : val[j]; srcg[pos] = pos | kFinalBit; }
+        else if (val[j] > pos) bad = true;           // a reference before the start of the image
+        else expand = true;
       }
-    }
-    uint64_t m = __ballot(expand && cnt > kWgOwnCopy);
-    while (m) {
-      const uint32_t l = (uint32_t)__builtin_ctzll(m);
-      m &= m - 1;
-      const uint32_t p2 = lane_read(pos, l), n2 = lane_read(cnt, l), dist = lane_read(val, l);
-      for (uint32_t c2 = 0; c2 < n2; c2 += 64) {
-        const uint32_t e = c2 + lane;
-        if (e < n2) srcg[p2 + e] = p2 - dist + (dist < n2 ? e % dist : e);
+      if (expand && cnt[j] <= kWgOwnCopy) {
+        if (val[j] >= cnt[j]) {
+          for (uint32_t e = 0; e < cnt[j]; e++) srcg[pos + e] = pos - val[j] + e;
+        } else {
+          for (uint32_t e = 0; e < cnt[j]; e++) srcg[pos + e] = pos - val[j] + e % val[j];
+        }
+      }
+      uint64_t m = __ballot(expand && cnt[j] > kWgOwnCopy);
+      while (m) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t p2 = lane_read(pos, l), n2 = lane_read(cnt[j], l), dist = lane_read(val[j], l);
+        for (uint32_t c2 = 0; c2 < n2; c2 += 64) {
+          const uint32_t e = c2 + lane;
+          if (e < n2) srcg[p2 + e] = p2 - dist + (dist < n2 ? e % dist : e);
+        }
       }
     }
     fill += all;
