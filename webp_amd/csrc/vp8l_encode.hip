@@ -1106,18 +1106,6 @@ __global__ __launch_bounds__(256) void k_parse_chain(const EncState *__restrict_
 // chains of dependent LDS reads that leave the memory system idle, the histogram is loads and LDS atomics, so the workgroups of
 // one CU overlap the two.  The histogram takes over the LDS of the advances once the marks are made.
 constexpr uint32_t kHistCopies = 3;  // interleaved copies of every counter: equal symbols in one wave meet less often
-__device__ __forceinline__ void histo_add(uint32_t *h, uint32_t sym) {
-  // One count per active lane.  Lanes that all hold the same symbol (an opaque alpha channel, a flat colour plane) would
-  // serialise on one LDS address: then one lane adds the number of lanes.
-  const uint64_t active = __ballot(1);
-  const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym);
-  if (__ballot(sym == first) == active) {
-    if ((uint32_t)__builtin_ctzll(active) == (threadIdx.x & 63u)) atomicAdd(&h[first * kHistCopies], (uint32_t)__popcll(active));
-  } else {
-    atomicAdd(&h[sym * kHistCopies + (threadIdx.x % kHistCopies)], 1u);
-  }
-}
-
 constexpr uint32_t kMarkThreads = 256;
 __global__ __launch_bounds__(kMarkThreads) void k_parse_mark(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                              const uint32_t *__restrict__ sb_first, uint32_t n,
@@ -1177,11 +1165,31 @@ __global__ __launch_bounds__(kMarkThreads) void k_parse_mark(const EncImage *__r
       if (!((f4 >> j) & 1u)) continue;
       const uint32_t m = mm[j], len = m & 0xff;
       if (len == 0) {
+        // One count per channel and active lane.  Lanes that all hold the same pixel (a flat area) or the same alpha (an
+        // opaque image) would serialise on one LDS address: then one lane adds the number of lanes.  One test per pixel
+        // and one for alpha: the other channels of a pixel that differs somewhere spread over the counters' copies.
         const uint32_t px = xx[j];
-        histo_add(&h[kGreen * kCodeStride * kHistCopies], (px >> 8) & 0xff);
-        histo_add(&h[kRed * kCodeStride * kHistCopies], (px >> 16) & 0xff);
-        histo_add(&h[kBlue * kCodeStride * kHistCopies], px & 0xff);
-        histo_add(&h[kAlpha * kCodeStride * kHistCopies], px >> 24);
+        const uint64_t active = __ballot(1);
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)px), diff = px ^ first;
+        const bool leader = (uint32_t)__builtin_ctzll(active) == (tid & 63u);
+        const uint32_t lanes = (uint32_t)__popcll(active), copy = tid % kHistCopies;
+        if (!__ballot(diff != 0)) {
+          if (leader) {
+            atomicAdd(&h[(kGreen * kCodeStride + ((first >> 8) & 0xff)) * kHistCopies], lanes);
+            atomicAdd(&h[(kRed * kCodeStride + ((first >> 16) & 0xff)) * kHistCopies], lanes);
+            atomicAdd(&h[(kBlue * kCodeStride + (first & 0xff)) * kHistCopies], lanes);
+            atomicAdd(&h[(kAlpha * kCodeStride + (first >> 24)) * kHistCopies], lanes);
+          }
+        } else {
+          atomicAdd(&h[(kGreen * kCodeStride + ((px >> 8) & 0xff)) * kHistCopies + copy], 1u);
+          atomicAdd(&h[(kRed * kCodeStride + ((px >> 16) & 0xff)) * kHistCopies + copy], 1u);
+          atomicAdd(&h[(kBlue * kCodeStride + (px & 0xff)) * kHistCopies + copy], 1u);
+          if (!__ballot((diff >> 24) != 0)) {
+            if (leader) atomicAdd(&h[(kAlpha * kCodeStride + (first >> 24)) * kHistCopies], lanes);
+          } else {
+            atomicAdd(&h[(kAlpha * kCodeStride + (px >> 24)) * kHistCopies + copy], 1u);
+          }
+        }
       } else {
         uint32_t sym, nb, eb;
         prefix_encode(len, sym, nb, eb);
