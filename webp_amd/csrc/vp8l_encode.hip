@@ -1344,6 +1344,17 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
       if (tid == 0) { if (pred) write_predictor_head(bw, pred_bits); else write_cross_color_head(bw, cross_bits); }
     }
     __syncthreads();
+    // Equal elements from each position on, at most 128 (matches are no longer): a mode image of a smooth picture is
+    // nearly one value, and comparing such candidates element by element cost a thread 128 steps for each of its up to
+    // 1023 candidates (5 ms per call on 64 photo-like 4K images); run by run it is one step.
+    uint16_t *runlen = sh.sub.lz.next_mis;  // (the host form's array; this search does not use it otherwise)
+    for (int p = (int)tid; p < np; p += 256) {
+      const uint32_t x = d[p];
+      int r = 1;
+      while (r < (int)kMaxLen && p + r < np && d[p + r] == x) r++;
+      runlen[p] = (uint16_t)r;
+    }
+    __syncthreads();
     for (int p = (int)tid; p < np; p += 256) {  // best match of every position, same rules as small_best_matches
       const int rem = np - p < (int)kMaxLen ? np - p : (int)kMaxLen;
       int best = 0, bestd = 0;
@@ -1352,8 +1363,12 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
         if (d[p - dd] != x) continue;
         const int maxl = dd < rem ? dd : rem;
         if (maxl < best) continue;  // cannot reach the best so far; an equally long, farther one replaces it
-        int l = 1;
-        while (l < maxl && d[p - dd + l] == d[p + l]) l++;
+        int l = 0;
+        do {  // both sides advance by whole runs
+          const int rq = runlen[p - dd + l], rp = runlen[p + l];
+          l += rq < rp ? rq : rp;
+        } while (l < maxl && d[p - dd + l] == d[p + l]);
+        l = l < maxl ? l : maxl;
         if (l >= best) { best = l; bestd = dd; }  // farthest among equals
       }
       if (rem <= 1) best = 0;
