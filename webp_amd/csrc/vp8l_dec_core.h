@@ -62,6 +62,7 @@ struct BitSrc {
 // kLutBits bits resolve in one lookup, longer ones by the per-length counts.
 constexpr int kLutBits = 10;
 constexpr uint16_t kLongCode = 0xffff;
+constexpr int kClLutBits = 7;  // lookup bits of the code-length code's table
 struct HuffTable {
   uint16_t lut[1 << kLutBits];  // (symbol << 4) | length; kLongCode = longer than kLutBits; a one-leaf code has length 0
   uint16_t count[kSaneCodeLen + 1];
@@ -78,10 +79,14 @@ struct GroupTables {
   uint16_t *sorted;  // kSortedPerGroup entries; only codes longer than the lookup table read it, so it may live in slow memory
 };
 
-VP8L_HD uint32_t dec_bit_reverse(uint32_t v, int len) {
+VP8L_HD uint32_t dec_bit_reverse(uint32_t v, int len) {  // 1 <= len <= 32
+#if defined(__clang__)
+  return __builtin_bitreverse32(v) >> (32 - len);
+#else
   uint32_t r = 0;
   for (int i = 0; i < len; i++) r |= ((v >> i) & 1u) << (len - 1 - i);
   return r;
+#endif
 }
 
 struct TableScratch {
@@ -93,7 +98,9 @@ struct TableScratch {
 // constructor accepts exactly the complete codes: every symbol gets its canonical code, a
 // collision or a missing leaf fails add_symbol / is_full.  A single used symbol becomes the root
 // whatever its length.  Lengths above 32 overflow the reference's 32-bit codes; rejected here.
-VP8L_HD int build_table(HuffTable &t, uint16_t *sorted, const uint8_t *lengths, int n, TableScratch &s) {
+// lut_bits: index bits of the lookup table that gets filled (the code-length code, read a few hundred times, gets a small one:
+// filling 1024 entries cost more than its symbols take to read).
+VP8L_HD int build_table(HuffTable &t, uint16_t *sorted, const uint8_t *lengths, int n, TableScratch &s, int lut_bits = kLutBits) {
   for (int l = 0; l <= kSaneCodeLen; l++) t.count[l] = 0;
   int used = 0, last = 0, maxl = 0;
   for (int i = 0; i < n; i++) {
@@ -110,7 +117,7 @@ VP8L_HD int build_table(HuffTable &t, uint16_t *sorted, const uint8_t *lengths, 
   if (used == 0) return kErrInvalidHuffman;
   if (used == 1) {
     t.single = (uint16_t)last;
-    for (int i = 0; i < (1 << kLutBits); i++) t.lut[i] = (uint16_t)(last << 4);
+    for (int i = 0; i < (1 << lut_bits); i++) t.lut[i] = (uint16_t)(last << 4);
     return kOk;
   }
   uint64_t kraft = 0;
@@ -126,15 +133,17 @@ VP8L_HD int build_table(HuffTable &t, uint16_t *sorted, const uint8_t *lengths, 
     t.first[l] = code;
     t.index[l] = s.off[l];
   }
-  for (int i = 0; i < (1 << kLutBits); i++) t.lut[i] = kLongCode;
+  // a complete code without long codes fills every entry below
+  if (maxl > lut_bits)
+    for (int i = 0; i < (1 << lut_bits); i++) t.lut[i] = kLongCode;
   for (int i = 0; i < n; i++) {
     const int l = lengths[i];
     if (!l) continue;
     sorted[s.off[l]++] = (uint16_t)i;
     const uint32_t c = s.next[l]++;
-    if (l <= kLutBits) {
+    if (l <= lut_bits) {
       const uint32_t r = dec_bit_reverse(c, l);
-      for (uint32_t k = r; k < (1u << kLutBits); k += 1u << l) t.lut[k] = (uint16_t)((i << 4) | l);
+      for (uint32_t k = r; k < (1u << lut_bits); k += 1u << l) t.lut[k] = (uint16_t)((i << 4) | l);
     }
   }
   return kOk;
@@ -161,9 +170,9 @@ VP8L_HD int build_simple(HuffTable &t, uint16_t *sorted, int nsym, uint32_t s0, 
   return kOk;
 }
 
-VP8L_HD uint32_t read_sym(BitSrc &br, const HuffTable &t, const uint16_t *sorted) {
+VP8L_HD uint32_t read_sym(BitSrc &br, const HuffTable &t, const uint16_t *sorted, int lut_bits = kLutBits) {
   const uint32_t bits = br.peek32();
-  const uint32_t e = t.lut[bits & ((1u << kLutBits) - 1u)];
+  const uint32_t e = t.lut[bits & ((1u << lut_bits) - 1u)];
   if (e != kLongCode) { br.skip(e & 15u); return e >> 4; }  // length 0: the symbol of a one-leaf code, no bits read
   uint32_t code = 0, first = 0, index = 0;
   for (int l = 1; l <= (int)t.maxlen; l++) {
@@ -295,7 +304,7 @@ VP8L_HD int read_code(BitSrc &br, int alphabet, HuffTable &t, uint16_t *sorted, 
   if (ncodes > (uint32_t)dl.ncl) return kErrInvalidHuffman;
   for (uint32_t i = 0; i < ncodes; i++) cl_len[dl.order((int)i)] = (uint8_t)br.get((uint32_t)dl.len_bits);
   sc.cl.sorted_off = 0;
-  int rc = build_table(sc.cl, sc.cl_sorted, cl_len, dl.ncl, sc.ts);
+  int rc = build_table(sc.cl, sc.cl_sorted, cl_len, dl.ncl, sc.ts, kClLutBits);
   if (rc < 0) return rc;
   uint32_t max_symbol;
   if (br.get(1)) {
@@ -310,7 +319,7 @@ VP8L_HD int read_code(BitSrc &br, int alphabet, HuffTable &t, uint16_t *sorted, 
   int sym = 0, prev = 8;
   while (sym < alphabet) {
     if (max_symbol-- == 0) break;
-    const uint32_t c = read_sym(br, sc.cl, sc.cl_sorted);
+    const uint32_t c = read_sym(br, sc.cl, sc.cl_sorted, kClLutBits);
     if (c < (uint32_t)dl.repeat) {
       lengths[sym++] = (uint8_t)c;
       if (c) prev = (int)c;
