@@ -471,9 +471,12 @@ __device__ __forceinline__ void wg_prepare_long(VP8L_LDS Sh &sh, const VP8L_LDS 
 // far (see wg_sym): set for images with a colour cache; a cache symbol then is a token of one pixel: cnt = 1, ref = true,
 // val = kWgCacheTok | index (the caller resolves it).
 constexpr uint32_t kWgCacheTok = 0x80000000u;  // no distance reaches this bit
+// alpha_single: the alpha code's only symbol when it has just one (an opaque image: the code takes no bits, and the lookup
+// that would say so is a fourth dependent LDS read per literal), else 0xffff.
 template <bool kValue = true, class Sh>
 __device__ __forceinline__ void wg_token(uint64_t w, const VP8L_LDS GroupTables &g, const VP8L_LDS Sh &sh, uint32_t xsize,
-                                         uint32_t &hop, uint32_t &cnt, uint32_t &val, bool &ref, const uint16_t *far = nullptr) {
+                                         uint32_t &hop, uint32_t &cnt, uint32_t &val, bool &ref, const uint16_t *far = nullptr,
+                                         uint32_t alpha_single = 0xffffu) {
   hop = 0; cnt = 0; val = 0; ref = false;
   uint32_t n = 0, S = 0;
   if (!wg_sym(w, n, g.t[kGreen], sh, kGreen, S, far)) return;
@@ -486,7 +489,9 @@ __device__ __forceinline__ void wg_token(uint64_t w, const VP8L_LDS GroupTables 
   }
   if (S < 256) {
     uint32_t r = 0, b = 0, a = 0;
-    if (!wg_sym(w, n, g.t[kRed], sh, kRed, r, far) || !wg_sym(w, n, g.t[kBlue], sh, kBlue, b, far) || !wg_sym(w, n, g.t[kAlpha], sh, kAlpha, a, far)) return;
+    if (!wg_sym(w, n, g.t[kRed], sh, kRed, r, far) || !wg_sym(w, n, g.t[kBlue], sh, kBlue, b, far)) return;
+    if (alpha_single != 0xffffu) a = alpha_single;
+    else if (!wg_sym(w, n, g.t[kAlpha], sh, kAlpha, a, far)) return;
     if (kValue) val = (a << 24) | (r << 16) | (S << 8) | b;
     cnt = 1;
     hop = n;
@@ -1431,6 +1436,7 @@ template <bool kRecord>
 __device__ __forceinline__ void lanes_pass(const LaneStream &ls, uint32_t s0, bool run, bool warm, uint32_t in, const VP8L_LDS GroupTables &g,
                                            VP8L_LDS LaneShared &sh, uint32_t xsize, uint32_t tid, uint64_t *rec, uint32_t cap,
                                            uint32_t r0, uint32_t &out, uint32_t &ntok, uint32_t &npx) {
+  const uint32_t alpha_single = g.t[kAlpha].single;  // the same for the whole workgroup
   uint64_t regs[kLaneChunkWords];
   ls.load(r0, tid, regs);
   ls.store(r0, tid, regs, sh);
@@ -1450,7 +1456,7 @@ __device__ __forceinline__ void lanes_pass(const LaneStream &ls, uint32_t s0, bo
       while (rel < lim) {
         uint32_t hop, cnt, val;
         bool ref;
-        wg_token<kRecord>(s ? (A >> s) | (B << (64 - s)) : A, g, sh, xsize, hop, cnt, val, ref);
+        wg_token<kRecord>(s ? (A >> s) | (B << (64 - s)) : A, g, sh, xsize, hop, cnt, val, ref, nullptr, alpha_single);
         if (hop == 0) {
           if (!warm) { stopped = true; break; }
           hop = 1;  // this need not be a token start, try the next bit
