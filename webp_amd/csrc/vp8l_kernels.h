@@ -87,20 +87,22 @@ __device__ __forceinline__ uint32_t find_image(const uint32_t *__restrict__ sb_f
   return lo;
 }
 
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+// Inclusive scan across the 64 lanes of a wave with DPP lane moves (no trips through the LDS crossbar, which a shuffle
+// is): doubling steps inside the rows of 16 lanes (lanes without a source add 0), then the total of row 0 into row 1
+// and of row 2 into row 3, then the total of rows 0-1 into rows 2 and 3.  Every lane must be active.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int /*lane*/) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
   return v;
 }
 
-// inclusive scan across the 64 lanes of a wave
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = (uint32_t)__shfl_up((int)v, o, 64);
-    if (lane >= o) v += t;
-  }
-  return v;
+// sum over the 64 lanes of a wave, in every lane (all lanes active)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v, 0), 63);
 }
 
 }  // namespace vp8l
