@@ -1679,18 +1679,24 @@ __global__ __launch_bounds__(kPlaceThreads) void k_par_place(const DecImage *__r
       const uint32_t idx = j * (kPlaceThreads / 64) + wave;
       const uint32_t before = idx ? lane_read(wsums, idx - 1) : 0u;
       const uint32_t pos = fill + before + incl[j] - cnt[j];
+      // The first pixel of a token gets its entry here whatever the token is (a literal points at itself, a reference
+      // at its source: one store for both, and the many references of one pixel are done with it); the other pixels of
+      // a reference follow in the loops below.
       bool expand = false;
       if (cnt[j] && pos < total) {
         if (pos + cnt[j] > total) bad = true;        // a reference that runs past the end of the image
-        else if (!ref[j]) { dst[pos] = fold_green ? add_green(val[j]) : val[j]; srcg[pos] = pos | kFinalBit; }
-        else if (val[j] > pos) bad = true;           // a reference before the start of the image
-        else expand = true;
+        else if (ref[j] && val[j] > pos) bad = true; // a reference before the start of the image
+        else {
+          if (!ref[j]) dst[pos] = fold_green ? add_green(val[j]) : val[j];
+          srcg[pos] = ref[j] ? pos - val[j] : pos | kFinalBit;
+          expand = ref[j] && cnt[j] > 1;
+        }
       }
       if (expand && cnt[j] <= kWgOwnCopy) {
         if (val[j] >= cnt[j]) {
-          for (uint32_t e = 0; e < cnt[j]; e++) srcg[pos + e] = pos - val[j] + e;
+          for (uint32_t e = 1; e < cnt[j]; e++) srcg[pos + e] = pos - val[j] + e;
         } else {
-          for (uint32_t e = 0; e < cnt[j]; e++) srcg[pos + e] = pos - val[j] + e % val[j];
+          for (uint32_t e = 1; e < cnt[j]; e++) srcg[pos + e] = pos - val[j] + e % val[j];
         }
       }
       uint64_t m = __ballot(expand && cnt[j] > kWgOwnCopy);
