@@ -214,6 +214,27 @@ std::vector<size_t> make_chunks(const std::vector<size_t> &bytes, size_t min_ite
   return first;
 }
 
+// Chunks of a decode call.  A chunk should be small, so that its download overlaps the decoding of the next ones, and
+// large enough for the decoder: the whole device works on any call with a few MiB of streams, however few they are, while
+// small calls give a stream one workgroup and need hundreds of streams to fill the device.  So a chunk closes at
+// `soft` bytes of pixels once it holds kDecodeChunkStreamBytes of streams or min_items streams, and at `hard` anyway.
+// (128 4K streams: one chunk 8.4 GP/s, chunks of 128 MiB of pixels 10.8, of 64 MiB 8.4.)
+constexpr size_t kDecodeChunkStreamBytes = (size_t)4 << 20;
+std::vector<size_t> make_decode_chunks(const std::vector<size_t> &bytes, const std::vector<size_t> &stream_bytes, size_t min_items,
+                                       size_t soft, size_t hard) {
+  std::vector<size_t> first(1, 0);
+  size_t acc = 0, count = 0, streams = 0;
+  for (size_t i = 0; i < bytes.size(); i++) {
+    const bool enough = count >= min_items || streams >= kDecodeChunkStreamBytes;
+    if (count && ((enough && acc + bytes[i] > soft) || acc + bytes[i] > hard)) { first.push_back(i); acc = 0; count = 0; streams = 0; }
+    acc += bytes[i];
+    streams += stream_bytes[i];
+    count++;
+  }
+  first.push_back(bytes.size());
+  return first;
+}
+
 // Runs work(lane, chunk) for every chunk on up to kLanes host threads; returns the first failure.
 template <class Work>
 int run_chunks(Pipeline *p, size_t nchunks, Work work) {
@@ -390,7 +411,7 @@ int decode_batch_impl(int device, size_t n, const uint8_t *const *data, const si
   if (rc != VP8L_OK) return rc;
   std::lock_guard<std::mutex> lock(p->mu);
   // streams that already fail here keep their status; the device sees only the others
-  std::vector<size_t> idx, bytes;
+  std::vector<size_t> idx, bytes, stream_bytes;
   for (size_t i = 0; i < n; i++) {
     argb[i] = nullptr;
     width[i] = height[i] = 0;
@@ -398,9 +419,10 @@ int decode_batch_impl(int device, size_t n, const uint8_t *const *data, const si
     if (status[i] != VP8L_OK) continue;
     idx.push_back(i);
     bytes.push_back((size_t)width[i] * height[i] * 4);
+    stream_bytes.push_back(len[i]);
   }
   if (idx.empty()) return VP8L_OK;
-  const std::vector<size_t> first = make_chunks(bytes, g_decode_chunk_streams, g_chunk_bytes, kDecodeChunkMaxBytes);
+  const std::vector<size_t> first = make_decode_chunks(bytes, stream_bytes, g_decode_chunk_streams, 2 * g_chunk_bytes, kDecodeChunkMaxBytes);
   for (int l = 0; l < g_lanes && l < (int)first.size() - 1; l++)
     if ((rc = lane_ready(p, p->lanes[l], false, 0)) != VP8L_OK) return rc;
   auto work = [&](Lane &lane, size_t c) -> int {
