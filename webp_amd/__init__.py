@@ -232,6 +232,13 @@ def decode_batch(streams, device=-1, devices=None):
 
 
 # ------------------------------------------------------------------ device-memory forms
+def c_array(ctype, values):
+    """A ctypes array of `ctype` holding `values`; an array of that type is passed through as it is."""
+    if isinstance(values, C.Array) and values._type_ is ctype:
+        return values
+    return (ctype * len(values))(*values)
+
+
 class Encoder:
     """Batch encoder context (vp8l_encoder_*).  Device pointers are plain integers, e.g.
     torch.Tensor.data_ptr() of uint8/int32 CUDA tensors."""
@@ -258,11 +265,12 @@ class Encoder:
         return lib().vp8l_encode_bound(w, h)
 
     def encode_device(self, d_argb_ptrs, widths, heights, d_out_ptr, out_cap):
-        """Returns (offsets, lengths, status) as numpy arrays."""
+        """Returns (offsets, lengths, status) as numpy arrays.  The three per-image arguments may be ctypes arrays made with
+        c_array() (a caller that repeats a call then does not pay for converting Python lists every time)."""
         n = len(d_argb_ptrs)
-        ptrs = (C.c_void_p * n)(*d_argb_ptrs)
-        ws = (C.c_uint32 * n)(*widths)
-        hs = (C.c_uint32 * n)(*heights)
+        ptrs = c_array(C.c_void_p, d_argb_ptrs)
+        ws = c_array(C.c_uint32, widths)
+        hs = c_array(C.c_uint32, heights)
         off = (C.c_size_t * n)()
         lens = (C.c_size_t * n)()
         status = (C.c_int * n)()
@@ -374,11 +382,11 @@ class Decoder:
 
     def decode_device(self, d_data_ptrs, lengths, widths, heights, d_argb_ptrs):
         n = len(d_data_ptrs)
-        dp = (C.c_void_p * n)(*d_data_ptrs)
-        ln = (C.c_size_t * n)(*lengths)
-        ws = (C.c_uint32 * n)(*widths)
-        hs = (C.c_uint32 * n)(*heights)
-        op = (C.c_void_p * n)(*d_argb_ptrs)
+        dp = c_array(C.c_void_p, d_data_ptrs)
+        ln = c_array(C.c_size_t, lengths)
+        ws = c_array(C.c_uint32, widths)
+        hs = c_array(C.c_uint32, heights)
+        op = c_array(C.c_void_p, d_argb_ptrs)
         status = (C.c_int * n)()
         rc = lib().vp8l_decoder_decode_device(self._h, n, dp, ln, ws, hs, op, status)
         if rc != OK:
