@@ -59,3 +59,13 @@ def test_binding_refuses_short_pixel_arrays():
     with pytest.raises(webp_amd.Vp8lError) as ei:
         webp_amd.encode_batch([(np.zeros(16, dtype=np.uint32), 4, 4), (short, 4, 4)])
     assert ei.value.name == "InvalidARGBImage"
+
+
+def test_c_array_passes_matching_arrays_through():
+    # per-image arguments of the device entry points: lists are converted, arrays made once are used as they are
+    a = webp_amd.c_array(C.c_uint32, [1, 2, 3])
+    assert list(a) == [1, 2, 3] and a._type_ is C.c_uint32
+    assert webp_amd.c_array(C.c_uint32, a) is a
+    b = webp_amd.c_array(C.c_size_t, a)  # another element type: converted
+    assert b is not a and list(b) == [1, 2, 3] and b._type_ is C.c_size_t
+    assert len(webp_amd.c_array(C.c_void_p, [])) == 0
