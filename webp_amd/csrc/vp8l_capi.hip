@@ -72,8 +72,8 @@ int env_int(const char *name, int fallback, int lo, int hi) {
 }
 const int g_lanes = env_int("VP8L_HOST_LANES", 8, 1, kLanes);
 const size_t g_chunk_bytes = (size_t)env_int("VP8L_HOST_CHUNK_MB", 64, 1, 4096) << 20;  // pixel bytes per encode chunk (at least one image)
-// The decoder runs one workgroup per stream and a stream takes as long as it takes: a chunk should hold enough
-// streams to fill the device, so chunks close at 256 streams (and at least the encode chunk size), or at 8 GiB of pixels.
+// Decode chunks (make_decode_chunks): twice the encode chunk size in pixels once a chunk holds a few MiB of streams or
+// this many streams (small calls give a stream one workgroup: it takes hundreds to fill the device), 8 GiB of pixels at most.
 const size_t g_decode_chunk_streams = (size_t)env_int("VP8L_HOST_DECODE_STREAMS", 256, 1, 1 << 20);
 constexpr size_t kDecodeChunkMaxBytes = (size_t)8 << 30;
 
