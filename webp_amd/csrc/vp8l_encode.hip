@@ -1085,19 +1085,62 @@ __global__ __launch_bounds__(128) void k_parse_exits(const EncImage *__restrict_
   sx[(size_t)sb * kBlockLen + tid] = (uint8_t)e;
 }
 
+// Per image: where the chain enters every superblock, from the superblocks' exit tables.  One entry value goes through
+// all of them, a chain of dependent lookups; 128 tables a round out of LDS, in three steps: every group of 8 tables is
+// composed into one (all threads: 16 groups x 128 entries, 8 lookups each), one thread takes the entry through the 16
+// group tables, 16 threads take their group's entry through its 8 tables.  (One thread walking all the tables took 0.57 ms
+// for a 16383 x 16383 image, a tenth of its encode time.)
 __global__ __launch_bounds__(256) void k_parse_chain(const EncState *__restrict__ st, const uint32_t *__restrict__ sb_first,
                                                      const uint8_t *__restrict__ sx, uint8_t *__restrict__ entry) {
-  __shared__ __attribute__((aligned(16))) uint8_t tab[128 * kBlockLen];
+  constexpr uint32_t kRound = 128, kGroup = 8, kGroups = kRound / kGroup;
+  __shared__ __attribute__((aligned(16))) uint8_t tab[kRound * kBlockLen];
+  __shared__ uint8_t gmap[kGroups * kBlockLen];  // exit of a group of tables for every entry
+  __shared__ uint8_t gent[kGroups];              // where the chain enters each group
+  __shared__ uint32_t s_e;
   const uint32_t img = blockIdx.x, tid = threadIdx.x;
   const uint32_t nsb = (st[img].M + kSuper - 1) / kSuper, sb0 = sb_first[img];
   uint32_t e = 0;
-  for (uint32_t g = 0; g < nsb; g += 128) {
-    const uint32_t cnt = nsb - g < 128 ? nsb - g : 128;
+  // a round's tables (16 KiB) are on their way from memory while the round before is walked: the load's latency, a
+  // microsecond or two, was most of a round's time
+  constexpr uint32_t kLoads = kRound * kBlockLen / 16 / 256;
+  uint4 ahead[kLoads];
+  auto fetch = [&](uint32_t g) {
+    const uint32_t cnt = nsb - g < kRound ? nsb - g : kRound;
     const uint4 *src = reinterpret_cast<const uint4 *>(sx + (size_t)(sb0 + g) * kBlockLen);
-    for (uint32_t i = tid; i < cnt * kBlockLen / 16; i += 256) reinterpret_cast<uint4 *>(tab)[i] = src[i];
+#pragma unroll
+    for (uint32_t k = 0; k < kLoads; k++) {
+      const uint32_t i = k * 256 + tid;
+      ahead[k] = i < cnt * kBlockLen / 16 ? src[i] : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if (nsb) fetch(0);
+  for (uint32_t g = 0; g < nsb; g += kRound) {
+    const uint32_t cnt = nsb - g < kRound ? nsb - g : kRound;
+#pragma unroll
+    for (uint32_t k = 0; k < kLoads; k++) reinterpret_cast<uint4 *>(tab)[k * 256 + tid] = ahead[k];
+    if (g + kRound < nsb) fetch(g + kRound);
     __syncthreads();
-    if (tid == 0)
-      for (uint32_t i = 0; i < cnt; i++) { entry[sb0 + g + i] = (uint8_t)e; e = tab[i * kBlockLen + e]; }
+    for (uint32_t k = tid; k < kGroups * kBlockLen; k += 256) {
+      const uint32_t grp = k / kBlockLen;
+      uint32_t x = k % kBlockLen;
+      for (uint32_t j = 0; j < kGroup && grp * kGroup + j < cnt; j++) x = tab[(grp * kGroup + j) * kBlockLen + x];
+      gmap[k] = (uint8_t)x;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t x = e;
+      for (uint32_t grp = 0; grp < kGroups; grp++) { gent[grp] = (uint8_t)x; x = gmap[grp * kBlockLen + x]; }
+      s_e = x;
+    }
+    __syncthreads();
+    if (tid < kGroups) {
+      uint32_t x = gent[tid];
+      for (uint32_t j = 0; j < kGroup && tid * kGroup + j < cnt; j++) {
+        entry[sb0 + g + tid * kGroup + j] = (uint8_t)x;
+        x = tab[(tid * kGroup + j) * kBlockLen + x];
+      }
+    }
+    e = s_e;
     __syncthreads();
   }
 }
