@@ -2209,14 +2209,17 @@ __global__ __launch_bounds__(64) void k_inverse_predictor_bands(const DecImage *
   const uint32_t steps = w + 2 * (rows_here - 1);
   bool bad = false, late = false;
   // waits until the band above has finished `need` pixels of its last row
+  uint32_t seen = 0;  // what the band above had finished when it was last asked (it only grows: no need to ask again below that)
   auto wait_for = [&](uint32_t need) {
     if (!theirs || late) return;
     need = need < w ? need : w;
+    if (seen >= need) return;  // a read past the caches takes a microsecond or two, and this is asked every eight steps
     for (uint32_t spin = 0;; spin++) {
       // relaxed, past the caches: the row above is read the same way, so no cache has to be invalidated for it
       const uint32_t have = uni(__hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      if (have >= need) return;
       if (have == 0xffffffffu || spin > (1u << 22)) { late = true; return; }  // the band above gave up, or is not coming
+      seen = have;
+      if (have >= need) return;
       __builtin_amdgcn_s_sleep(8);
     }
   };
