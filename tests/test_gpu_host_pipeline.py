@@ -63,6 +63,41 @@ def test_many_chunks_few_lanes():
     assert "pipeline ok" in r.stdout
 
 
+CHILD_LARGE = textwrap.dedent("""
+    import sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    sys.path.insert(0, %r)
+    import _oracle as O
+    import webp_amd
+
+    # streams of more than a MiB each: a decode chunk closes by its pixel bytes as soon as it holds a few MiB of streams
+    imgs = [(O.gen_image(3, 1000, 700, 300 + k), 1000, 700) for k in range(12)]
+    res = webp_amd.encode_batch(imgs)
+    assert all(st == 0 for st, _ in res)
+    streams = [data for _, data in res]
+    assert sum(len(s) for s in streams[:5]) > (4 << 20)
+    streams[7] = streams[7][: len(streams[7]) // 3]   # one damaged stream in the middle of a chunk
+    out = webp_amd.decode_batch(streams)
+    for k, ((st, arr, w, h), (img, w0, h0)) in enumerate(zip(out, imgs)):
+        if k == 7:
+            rc0, ref, w1, h1 = O.decode(streams[7])   # the oracle's verdict on the damaged stream, whatever it is
+            assert st == rc0
+            assert rc0 != 0 or ((w, h) == (w1, h1) and np.array_equal(arr, ref))
+        else:
+            assert st == 0 and (w, h) == (w0, h0) and np.array_equal(arr, img), k
+    print("large ok")
+""")
+
+
+def test_large_streams_chunked_by_pixel_bytes():
+    env = dict(os.environ, VP8L_HOST_LANES="2", VP8L_HOST_CHUNK_MB="4")
+    code = CHILD_LARGE % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "large ok" in r.stdout
+
+
 def test_batch_dealt_out_to_a_device_list():
     """vp8l_encode_batch_devices / vp8l_decode_batch_devices: the device list may name one GPU several times (this box has
     one), which runs every block on its own host thread against the same device: every image is encoded exactly once, in
