@@ -159,3 +159,22 @@ def test_random_run_structures(seed):
     img = np.concatenate(pieces)[:12000]
     check(img, 12000, 1)
     check(img, 100, 120)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_matches_ending_just_past_the_length_limit(seed):
+    # Copies of one long pattern, each spoilt at a few places: at most positions several distances match for 128 pixels
+    # and more and end at different places above the limit, where the farthest must win and not the one that goes on
+    # longest; flat stretches in between give matches that their own distance cuts.
+    rng = np.random.default_rng(500 + seed)
+    n = 14000
+    period = int(rng.choice([131, 200, 517]))
+    base = rng.integers(0, 1 << 24, size=period, dtype=np.uint32) | np.uint32(0xFF000000)
+    a = np.tile(base, n // period + 1)[:n].copy()
+    for p in rng.integers(0, n, size=n // 90):
+        a[p] ^= np.uint32(1 + int(rng.integers(0, 255)))
+    for k in range(12):
+        s = int(rng.integers(0, n - 400))
+        a[s: s + int(rng.integers(2, 300))] = np.uint32(0xFF000000 | int(rng.integers(0, 1 << 24)))
+    check(a, n, 1)
+    check(a, 125, n // 125)

@@ -287,45 +287,76 @@ __device__ __forceinline__ void load16(const uint32_t *__restrict__ src, uint32_
   L[8] = v2.x; L[9] = v2.y; L[10] = v2.z; L[11] = v2.w; L[12] = v3.x; L[13] = v3.y; L[14] = v3.z; L[15] = v3.w;
 }
 
+__device__ __forceinline__ uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c) { a = a < b ? a : b; return a < c ? a : c; }
+__device__ __forceinline__ uint32_t max3_u32(uint32_t a, uint32_t b, uint32_t c) { a = a > b ? a : b; return a > c ? a : c; }
+
 // One chunk of 16 positions P, P-1, .., P-15 (P = 15 mod 16).  EMIT: the positions belong to the
 // tile (best matches are produced); otherwise they only warm the run state up.
-// One "slot" = the 64 cells (lanes) of one j.  Most slots of natural images hold no equal pixel:
-// their compare mask is empty, every run of the slot ends here and nothing can match, so the slot
-// costs one compare and one move.  The test is on the scalar (wave-uniform) compare mask.
-template <bool HEAD, bool EMIT>
-__device__ __forceinline__ uint32_t lz77_chunk(uint32_t (&mis)[16], const uint32_t (&win)[31], const uint32_t (&cap)[31],
-                                               const uint32_t xcur, const int P, const uint32_t M, const int lane) {
+// One "slot" = the 64 cells (lanes) of one j.  A cell's state is (first mismatch << 4 | j), so the largest state of a
+// lane names its cell.  Positions are counted within groups of four (3, 2, 1, 0 from the top; every state moves up by 4
+// after a group), which keeps the value a cell takes on a mismatch, position << 4 | j, below 64: an inline constant of
+// the select instruction, which can read neither a literal nor a scalar register beside its mask.
+// A position's best match is found in two steps.  First the largest state of the wave, without the limits of a match
+// (it cannot overlap its source: at most its distance; at most 128 pixels): three instructions per cell less than
+// limiting every cell.  If the limits do not touch the winning cell, it is the best match: no other cell's limited
+// value exceeds its own state, so none exceeds the winner's, and an equal one is nearer by the packing.  Otherwise the
+// position is scored again with the limits applied to every cell, and counted in `rescored`.
+// CAP: every state is first cut to 128 pixels above the position (one more instruction per cell).  Cut states stay
+// valid, the limit only falls from one position to the next below it.  With it, matches of 128 pixels and more (cells
+// above the limit by different amounts, where the farthest must win) need no second scoring; the caller switches it
+// on per chunk where such matches are.
+template <bool HEAD, bool EMIT, bool CAP>
+__device__ __forceinline__ uint32_t lz77_chunk(uint32_t (&mis)[16], const uint32_t (&win)[31], const uint32_t xcur, const int P,
+                                               const uint32_t M, const int lane, uint32_t &rescored) {
   uint32_t res = 0;  // lane s: packed (end of best match << 10 | distance-1) of position P-s
 #pragma unroll
   for (int s = 0; s < 16; s++) {
     const uint32_t p = (uint32_t)(P - s);
-    if (p >= M) continue;  // past the end of the image (last chunk only)
-    const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xcur, 15 - s);  // data[p], the same for all lanes
-    const uint32_t here = 16u - (uint32_t)s;
-    const uint32_t lim = here + kMaxLen;  // at most 128 pixels
-    uint32_t key = 0;
+    const uint32_t here = 3u - ((uint32_t)s & 3u);
+    if (p < M) {  // else past the end of the image (last chunk only)
+      const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xcur, 15 - s);  // data[p], the same for all lanes
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      bool eq = win[s + j] == x;
-      if (HEAD) eq = eq && (uint32_t)(16 * lane + j + 1) <= p;  // distances reaching before the first pixel never match
-      mis[j] = eq ? mis[j] : here;
-      if (EMIT && __builtin_expect(__ballot(eq) != 0, 0)) {
-        uint32_t t = mis[j] < cap[j - s + 15] ? mis[j] : cap[j - s + 15];
-        t = t < lim ? t : lim;
-        const uint32_t kj = (t << 4) | (uint32_t)j;
-        key = key > kj ? key : kj;
+      for (int j = 0; j < 16; j++) {
+        bool eq = win[s + j] == x;
+        // distance 16 * lane + j + 1 <= p: those reaching before the first pixel never match.  (The right side is kept a
+        // scalar on purpose: moved to the left, the compiler holds 31 sums in vector registers for the whole kernel.)
+        if (HEAD) eq = eq && 16 * lane + 1 <= __builtin_amdgcn_readfirstlane((int)p - j);
+        uint32_t m = mis[j];
+        if (EMIT && CAP) m = m < (((here + kMaxLen) << 4) | (uint32_t)j) ? m : (((here + kMaxLen) << 4) | (uint32_t)j);
+        mis[j] = eq ? m : ((here << 4) | (uint32_t)j);
+      }
+      if (EMIT) {
+        // (end of match, distance-1): the largest distance wins among equal lengths (lz77.h:68).
+        // No equal pixel anywhere in the window: every state is `here`, length 0.
+        uint32_t m = max3_u32(mis[0], mis[1], mis[2]);
+        m = max3_u32(m, mis[3], mis[4]);
+        m = max3_u32(m, mis[5], mis[6]);
+        m = max3_u32(m, mis[7], mis[8]);
+        m = max3_u32(m, mis[9], mis[10]);
+        m = max3_u32(m, mis[11], mis[12]);
+        m = max3_u32(m, mis[13], mis[14]);
+        m = m > mis[15] ? m : mis[15];
+        uint32_t K = wave_max_dpp(((m & ~15u) << 6) | ((uint32_t)lane << 4) | (m & 15u));
+        const uint32_t dist = (K & 1023u) + 1u;
+        if ((K >> 10) > here + (dist < kMaxLen ? dist : kMaxLen)) {  // the limits cut the winner: apply them to every cell
+          rescored++;
+          const uint32_t lim = ((here + kMaxLen) << 4) | 15u;
+          const uint32_t cap0 = ((16u * (uint32_t)lane + 1u + here) << 4) | 15u;  // position + distance of cell 0
+          uint32_t key = 0;
+#pragma unroll
+          for (int j = 0; j < 16; j++) {
+            const uint32_t t = min3_u32(mis[j], cap0 + ((uint32_t)j << 4), lim);
+            const uint32_t kj = (t & ~15u) | (uint32_t)j;
+            key = key > kj ? key : kj;
+          }
+          K = wave_max_dpp(((key & ~15u) << 6) | ((uint32_t)lane << 4) | (key & 15u));
+        }
+        res = lane == s ? K : res;
       }
     }
-    if (EMIT) {
-      // (end of match, distance-1): the largest distance wins among equal lengths (lz77.h:68).
-      // key == 0: no equal pixel anywhere in the window, length 0.
-      uint32_t K = (here << 10);
-      if (__builtin_expect(__ballot(key != 0) != 0, 1)) {
-        K = ((key & ~15u) << 6) | ((uint32_t)lane << 4) | (key & 15u);
-        K = wave_max_dpp(K);
-        if (K < (here << 10)) K = here << 10;
-      }
-      res = lane == s ? K : res;
+    if ((s & 3) == 3) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) mis[j] += 4u << 4;
     }
   }
   return res;
@@ -340,15 +371,15 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
   const int ctop = (int)(qs >> 4);
   const int cbot = (int)(a >> 4);
   int P = ctop * 16 + 15;
-  uint32_t mis[16];  // per distance: first mismatch position at or after the current one (chunk relative)
+  uint32_t mis[16];  // per distance: first mismatch position at or after the current one (see lz77_chunk) << 4 | j
   {
-    const uint32_t lim = ((uint32_t)P + 1 < M ? (uint32_t)P + 1 : M) - (uint32_t)P + 16;
+    const uint32_t lim = ((uint32_t)P + 1 < M ? (uint32_t)P + 1 : M) - (uint32_t)P + 3;
 #pragma unroll
-    for (int j = 0; j < 16; j++) mis[j] = lim;
+    for (int j = 0; j < 16; j++) mis[j] = (lim << 4) | (uint32_t)j;
   }
-  uint32_t cap[31];  // cap[j - s + 15] = (position + distance) in chunk coordinates: a match cannot overlap its source
-#pragma unroll
-  for (int k = 0; k < 31; k++) cap[k] = 16u * (uint32_t)lane + 2u + (uint32_t)k;
+  // Whether the chunks cut their states to 128 pixels (see lz77_chunk): not while few of a chunk's positions have to be
+  // scored again, and for the next eight chunks after a chunk where three or more had to.
+  uint32_t cap_chunks = 0;
   uint32_t win[31];  // win[k] = data[P - 16*lane - 1 - k]
   uint32_t nxt[16];  // the 16 pixels that enter the window with the next chunk (loaded one chunk ahead)
   uint32_t xnext;    // lane k (< 16): pixel P-15+k of the next chunk
@@ -376,11 +407,18 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
       xnext = data[P - 31 + (lane & 15)];
     }
     if ((uint32_t)(P - 15) < b) {
-      const uint32_t res = lz77_chunk<HEAD, true>(mis, win, cap, xcur, P, M, lane);
+      uint32_t rescored = 0, res;
+      if (cap_chunks) {
+        cap_chunks--;
+        res = lz77_chunk<HEAD, true, true>(mis, win, xcur, P, M, lane, rescored);
+      } else {
+        res = lz77_chunk<HEAD, true, false>(mis, win, xcur, P, M, lane, rescored);
+        if (rescored >= 3) cap_chunks = 8;
+      }
       if (lane < 16) {
         const uint32_t p = (uint32_t)(P - lane);
         if (p < b && p < M) {
-          uint32_t len = (res >> 10) - (16u - (uint32_t)lane);
+          uint32_t len = (res >> 10) - (3u - ((uint32_t)lane & 3u));
           const uint32_t dist = (res & 1023u) + 1u;
           if (p == M - 1) len = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
           match[p] = len ? (len | (dist << 8) | (dist_to_code_inv(xsize, xinv, dist) << 19)) : 0u;
@@ -388,12 +426,11 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
         }
       }
     } else {
-      (void)lz77_chunk<HEAD, false>(mis, win, cap, xcur, P, M, lane);
+      uint32_t unused = 0;
+      (void)lz77_chunk<HEAD, false, false>(mis, win, xcur, P, M, lane, unused);
     }
 #pragma unroll
     for (int k = 0; k < 15; k++) win[k] = win[k + 16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) mis[j] += 16;
   }
 }
 
@@ -1011,7 +1048,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   VP8L_PHASE_MARK(6);  // results stored
 }
 
-__global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+__global__ __launch_bounds__(256, 4) void k_lz77(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                               const uint32_t *__restrict__ sb_first, uint32_t n,
                                               const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                               uint8_t *__restrict__ adv, const uint8_t *__restrict__ dense_tile) {
@@ -1022,13 +1059,32 @@ __global__ __launch_bounds__(256) void k_lz77(const EncImage *__restrict__ imgs,
   const uint32_t M = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[img].M);
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t a = (blk - sb_first[img] * kPerSuper) * kLzBlock + wave * kLzTile;
-  if (a >= M) return;
+  uint32_t a = (blk - sb_first[img] * kPerSuper) * kLzBlock + wave * kLzTile;
   const uint32_t b = a + kLzTile < M ? a + kLzTile : M;
+  if (a == 0) a = kLzHead;  // the first positions of an image are k_lz77_head's
+  if (a >= b) return;
   const uint64_t pos0 = imgs[img].pos0;
   const uint32_t xsize = st[img].xsize, xinv = st[img].xinv;
-  if (a == 0) lz77_tile<true>(pix + pos0, match + pos0, adv + pos0, M, a, b, lane, xsize, xinv);
-  else lz77_tile<false>(pix + pos0, match + pos0, adv + pos0, M, a, b, lane, xsize, xinv);
+  lz77_tile<false>(pix + pos0, match + pos0, adv + pos0, M, a, b, lane, xsize, xinv);
+}
+
+// The first kLzHead positions of every image: there, distances reach before the first pixel.  A kernel of its own,
+// because testing for that costs 40 vector registers more, and the kernel above runs four waves per SIMD without them;
+// in pieces of 128 positions, a wave each, so that it does not take as long as a whole tile does.
+__global__ __launch_bounds__(64) void k_lz77_head(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                  const uint32_t *__restrict__ sb_first, uint32_t n,
+                                                  const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
+                                                  uint8_t *__restrict__ adv, const uint8_t *__restrict__ dense_tile) {
+  const uint32_t img = blockIdx.x / (kLzHead / kLzHeadPiece);
+  if (img >= n) return;
+  if (dense_tile && __builtin_amdgcn_readfirstlane((int)dense_tile[(size_t)sb_first[img] * (kSuper / kLzTile)]) == 0) return;
+  const uint32_t M = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[img].M);
+  const uint32_t a = (blockIdx.x % (kLzHead / kLzHeadPiece)) * kLzHeadPiece;
+  uint32_t b = a + kLzHeadPiece;
+  b = b < M ? b : M;
+  if (a >= b) return;
+  const uint64_t pos0 = imgs[img].pos0;
+  lz77_tile<true>(pix + pos0, match + pos0, adv + pos0, M, a, b, (int)threadIdx.x, st[img].xsize, st[img].xinv);
 }
 
 // =============================================================================================
@@ -1923,6 +1979,8 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
                        gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0], g_tune[1], g_tune[2]);
   mark(9);  // also when the candidate-list kernel is switched off
   hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,
+                     match_mode == 0 ? B.dense : (const uint8_t *)nullptr);
+  hipLaunchKernelGGL(k_lz77_head, dim3(nl * (kLzHead / kLzHeadPiece)), dim3(64), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,
                      match_mode == 0 ? B.dense : (const uint8_t *)nullptr);
   mark(3);
   hipLaunchKernelGGL(k_parse_exits, dim3(gsb), dim3(128), 0, s, B.imgs, B.st, B.sbf, nl, B.adv8, B.sx);

@@ -19,6 +19,8 @@ constexpr uint32_t kUnitsPerSuper = kSuper / kUnit;
 constexpr uint32_t kLzTile = 2048;      // positions per match-search wave
 constexpr uint32_t kLzWaves = 4;        // waves per match-search block
 constexpr uint32_t kLzBlock = kLzTile * kLzWaves;
+constexpr uint32_t kLzHead = 1024;      // positions at the start of an image that have fewer than 1024 distances (= the window)
+constexpr uint32_t kLzHeadPiece = 128;  // ... searched in pieces of this many
 constexpr uint32_t kTailPad = 64;       // readable slack behind every image's region
 
 struct EncImage {          // host-written
