@@ -686,7 +686,7 @@ constexpr uint32_t kSpMul = 0x9E3779B1u;             // odd: x -> x * kSpMul is 
                                                      // same bucket + same tag <=> same pixel value
 constexpr uint32_t kSpMaxBucket = 192;   // a bucket this full means heavy duplication: not a sparse tile
 constexpr uint32_t kSpHeavyBucket = 24;  // no bucket this full: the tile is sparse, no need to count its values
-constexpr uint32_t kSpMaxPerValue = 6;   // more run starts per distinct value than this on average: not a sparse tile
+constexpr uint32_t kSpMaxMeanBucket = 30;  // an entry shares its bucket with more than this many on average: not a sparse tile
 constexpr uint32_t kSpBudget = 700;      // candidate tests + extension steps one thread may spend (4 positions)
 constexpr uint32_t kSpSeg = 7;           // window pixels per thread in the run-length pass
 static_assert(kSpSources <= (1u << kSpPosBits) && kSpSources % kSpThreads == 0 && kSpTile % kSpThreads == 0, "entry layout");
@@ -702,7 +702,7 @@ static_assert(kSpTile / kSpThreads == 4, "positions of a thread are handled as t
 __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                      const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
                                                      uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
-                                                     uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile, uint32_t tune_per_value,
+                                                     uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile, uint32_t tune_mean_bucket,
                                                      uint32_t tune_budget, uint32_t tune_max_bucket) {
   __shared__ __attribute__((aligned(16))) uint32_t px[kSpSources + kMaxLen + 4];
   // Tiles with runs: runlen[i] = pixels equal to pixel i from there on (within the window), 16 bits each.  Tiles without
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   __shared__ uint32_t items[kSpSources];   // (low bits of the mixed pixel) << 11 | index in px
   __shared__ uint32_t wsum[kSpWaves];
   __shared__ uint32_t wmin[kSpWaves];
-  __shared__ uint32_t s_abort, s_inside, s_nonempty, s_heavy;
+  __shared__ uint32_t s_abort, s_inside, s_sumsq, s_heavy;
   constexpr uint32_t kPerSuper = kSuper / kSpTile;
   // Workgroups go round-robin to the 8 XCDs, each with its own L2.  Neighbouring tiles share half of their
   // window, so every XCD takes one contiguous eighth of the tiles: the overlap is then read from its L2, not twice from HBM.
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   const uint32_t lane = tid & 63, wave = tid >> 6;
   VP8L_PHASE_BEGIN();
   for (uint32_t i = tid; i < kSpBuckets / 2; i += kSpThreads) cursor2[i] = 0;
-  if (tid == 0) { s_abort = 0; s_inside = 0; s_nonempty = 0; s_heavy = 0; }
+  if (tid == 0) { s_abort = 0; s_inside = 0; s_sumsq = 0; s_heavy = 0; }
   // lo is a multiple of 4 (a and kWindow are) and the pixel array has readable slack past M: 16-byte loads
   if (st[img].fused) {
     // Subtract-green path: the residual is made here from the caller's pixels (vp8l.h:594-597,
@@ -844,15 +844,19 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   if (s_heavy) {
     // Some value is frequent.  Many entries of few values (two-colour noise bundled eight pixels to a word, 16 colours
     // two to a word): every position has dozens of candidates that extend a little, and the exhaustive kernel is
-    // cheaper than finding that out by running out of budget.  Counted on the scalar unit; other tiles skip this.
-    uint32_t nz = 0;
+    // cheaper than finding that out by running out of budget.  The measure is the bucket length an entry sees on
+    // average, sum of squares over sum: a position tests about a third of that many candidates (the window is a
+    // third of the sources).  The count per distinct value, used before, sent predictor residuals of photographs away
+    // too (500 values, 6 entries each, but 6 candidates per position: 1.6 times faster here than there).
+    uint32_t sq = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) nz += (uint32_t)__popcll(__ballot(c[k] != 0));
-    if (lane == 0 && nz) atomicAdd(&s_nonempty, nz);
+    for (int k = 0; k < 8; k++) sq += c[k] * c[k];
+    sq = wave_sum_u32(sq);
+    if (lane == 0 && sq) atomicAdd(&s_sumsq, sq);
     __syncthreads();
     uint32_t entries = 0;
     for (uint32_t k = 0; k < kSpWaves; k++) entries += wsum[k];
-    if (entries > tune_per_value * s_nonempty) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
+    if (s_sumsq > tune_mean_bucket * entries) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -930,12 +934,17 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
         }
         return !cand || fits;
       };
-#pragma unroll 1
+      // A source whose second pixel differs matches for one pixel whatever else holds, and among those the farthest
+      // wins: they need no scoring, only the largest distance (kept here per round as key 1 << 11 | distance).  Where
+      // few values make up much of a tile (predictor residuals), these are nearly all the candidates.
+      uint32_t one_pixel[2] = {0, 0};
+#pragma unroll
       for (uint32_t kk = 0; kk < 2; kk++) {
         const uint32_t ip = ip0 + kk * kSpThreads + lane;
-        uint32_t i = 0, end = 0, tag = 0, span = 0;
+        uint32_t i = 0, end = 0, tag = 0, span = 0, x1 = 0;
         if (lo + ip < b) {
           const uint32_t x = px[ip], mxd = x * kSpMul, h = mxd >> (32 - kSpPosBits);
+          x1 = px[ip + 1];
           tag = mxd << kSpTagShift;
           end = cursor[h];
           i = h ? cursor[h - 1] : 0u;
@@ -951,6 +960,11 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
           if (live) {
             t = items[i] ^ tag;
             cand = ip - 1 - t < span;
+            if (cand && px[t + 1] != x1) {
+              const uint32_t k1 = (1u << 11) | (ip - t);
+              one_pixel[kk] = one_pixel[kk] > k1 ? one_pixel[kk] : k1;
+              cand = false;
+            }
           }
           const bool taken = offer(cand, t, kk);  // by every lane: the queue is the wave's
           if (live && taken) { i++; spent++; }
@@ -962,6 +976,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
         const uint32_t p = lo + ip0 + kk * kSpThreads + lane;
         if (p < b) {
           uint32_t key = keys[kk * 64 + lane];
+          key = key > one_pixel[kk] ? key : one_pixel[kk];
           if (p == M - 1) key = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
           const uint32_t o = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_code_of(xsize, xinv, key & 2047u) << 19)) : 0u;
           match[pos0 + p] = o;
@@ -1917,9 +1932,9 @@ struct vp8l_encoder {
   double stage_seconds[9] = {};
 };
 
-// Heuristics of the candidate-list kernel (when a tile goes to the exhaustive kernel instead); VP8L_TUNE="per_value,budget,max_bucket"
+// Heuristics of the candidate-list kernel (when a tile goes to the exhaustive kernel instead); VP8L_TUNE="mean_bucket,budget,max_bucket"
 // overrides them for measurements.
-static uint32_t g_tune[3] = {kSpMaxPerValue, kSpBudget, kSpMaxBucket};
+static uint32_t g_tune[3] = {kSpMaxMeanBucket, kSpBudget, kSpMaxBucket};
 static const bool g_tune_read = [] {
   const char *v = getenv("VP8L_TUNE");
   if (v) sscanf(v, "%u,%u,%u", &g_tune[0], &g_tune[1], &g_tune[2]);
