@@ -178,3 +178,15 @@ def test_matches_ending_just_past_the_length_limit(seed):
         a[s: s + int(rng.integers(2, 300))] = np.uint32(0xFF000000 | int(rng.integers(0, 1 << 24)))
     check(a, n, 1)
     check(a, 125, n // 125)
+
+
+@pytest.mark.parametrize("m", [1023, 1024, 1025, 1040, 1151, 2047, 2048, 2049, 3071, 3073])
+def test_sizes_around_the_head_of_an_image(m):
+    # The first 1024 positions of an image, where distances reach before the first pixel, are searched by a kernel of
+    # their own in the exhaustive form; images that end just before, at and just behind that border and a tile's end.
+    rng = np.random.default_rng(m)
+    vals = rng.integers(0, 1 << 24, size=300, dtype=np.uint32) | np.uint32(0xFF000000)
+    img = vals[rng.integers(0, 300, size=m)]
+    img[: m // 2] = np.repeat(img[: m // 2: 3], 3)[: m // 2]  # short runs in the first half
+    img[m // 3: m // 3 + 40] = img[0:40]                      # a copy of the image's first pixels
+    check(img, m, 1)
