@@ -8,8 +8,9 @@
 //   k_pred_modes / k_pred_residual        optional forward predictor (inverse: transform.h:110-191)
 //   k_lz77_sparse                         LZ77<uint32_t>::pack best match at every position, from candidate
 //                                         lists (also makes the subtract-green residual when it can)
-//   k_lz77                                the same by testing all 1024 distances: fallback for tiles the
-//                                         candidate lists give up on                  lz77.h:51-72
+//   k_lz77 / k_lz77_head                  the same by testing all 1024 distances: fallback for tiles the
+//                                         candidate lists give up on (_head: an image's first 1024 positions)
+//                                                                                     lz77.h:51-72
 //   k_parse_exits / k_parse_chain / k_parse_mark   the greedy parse (which positions start a token)
 //                                                                  lz77.h:33-92
 //                                         (k_parse_mark also counts the symbols: the five histograms, vp8l.h:516-535)
@@ -263,8 +264,8 @@ __global__ __launch_bounds__(256) void k_transform(const EncImage *__restrict__ 
 // data[p-16l-16 .. p-16l-1]: a window that slides by one pixel per step, held in registers and
 // refilled with one 64-byte load per 16 steps.  Cost is 1024 cell updates per position
 // whatever the image content.  Positions are handled in aligned chunks of 16 and coordinates are
-// kept relative to the chunk (pos - P + 16, P = last position of the chunk) so every per-step
-// constant is a small literal.
+// kept relative to the current group of four positions (see lz77_chunk) so every per-step
+// constant is an inline constant.
 // =============================================================================================
 // max over the 64 lanes with DPP lane moves fused into the max (no LDS round trips); the result
 // is read from lane 63 into an SGPR.  Each step reads the register the previous VALU instruction
