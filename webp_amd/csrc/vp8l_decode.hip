@@ -2250,8 +2250,10 @@ __global__ __launch_bounds__(64) void k_inverse_predictor_bands(const DecImage *
       if (r == rows_here - 1) {
         const int xdone = (int)t - 2 * (int)r;  // pixels 0 .. xdone-1 of this row are stored
         if (xdone > 0) {
-          // the row's pixels were stored past the caches; once they have arrived (no cache write-back needed) the count follows
+          // the row's pixels were stored past the caches; once they have arrived (no cache write-back needed) the count
+          // follows.  The wait is spelled out: a workgroup-scope release need not wait for stores to global memory.
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __hip_atomic_store(mine, (uint32_t)xdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
@@ -2288,6 +2290,7 @@ __global__ __launch_bounds__(64) void k_inverse_predictor_bands(const DecImage *
   }
   if (r == rows_here - 1) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row's last pixels have arrived before the count says so
     __hip_atomic_store(mine, late ? 0xffffffffu : w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (late) atomicExch(&res[img].status, kPredRetry);
