@@ -190,3 +190,22 @@ def test_sizes_around_the_head_of_an_image(m):
     img[: m // 2] = np.repeat(img[: m // 2: 3], 3)[: m // 2]  # short runs in the first half
     img[m // 3: m // 3 + 40] = img[0:40]                      # a copy of the image's first pixels
     check(img, m, 1)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_few_frequent_values_without_runs(seed):
+    # A skewed alphabet (a few values hold a few per cent of the pixels each) and hardly any equal neighbours: tiles stay
+    # on the candidate lists with full buckets, whose entries are then kept group by group and walked from either end.
+    rng = np.random.default_rng(900 + seed)
+    nv = 700
+    vals = rng.integers(0, 1 << 24, size=nv, dtype=np.uint32) | np.uint32(0xFF000000)
+    wts = 1.0 / (np.arange(nv) + 6.0)
+    idx = rng.choice(nv, size=15000, p=wts / wts.sum())
+    same = np.flatnonzero(idx[1:] == idx[:-1]) + 1
+    idx[same] = (idx[same] + 1 + rng.integers(0, 5, size=same.size)) % nv  # break up most runs
+    img = vals[idx]
+    img[9000:9300] = img[2000:2300]  # long matches far back, across a group border
+    img[12000:12040] = img[11500:11540]
+    dense, total = check(img, 15000, 1)
+    assert dense < total, (dense, total)
+    check(img, 125, 120)
