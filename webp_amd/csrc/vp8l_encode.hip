@@ -688,6 +688,8 @@ constexpr uint32_t kSpMul = 0x9E3779B1u;             // odd: x -> x * kSpMul is 
 constexpr uint32_t kSpMaxBucket = 192;   // a bucket this full means heavy duplication: not a sparse tile
 constexpr uint32_t kSpHeavyBucket = 24;  // no bucket this full: the tile is sparse, no need to count its values
 constexpr uint32_t kSpMaxMeanBucket = 30;  // an entry shares its bucket with more than this many on average: not a sparse tile
+constexpr uint32_t kSpPairsMeanBucket = 8;  // from this mean bucket length on, a tile without runs is searched through pairs of pixels
+constexpr uint32_t kSpPairsGrid = 4096;     // workgroups of k_lz77_pairs (four fit a CU)
 constexpr uint32_t kSpBudget = 700;      // candidate tests + extension steps one thread may spend (4 positions)
 constexpr uint32_t kSpSeg = 7;           // window pixels per thread in the run-length pass
 static_assert(kSpSources <= (1u << kSpPosBits) && kSpSources % kSpThreads == 0 && kSpTile % kSpThreads == 0, "entry layout");
@@ -700,11 +702,17 @@ constexpr uint32_t kSpAuxWords = (kSpSources + kMaxLen) / 2;
 static_assert(kSpWaves * kSpWaveAux <= kSpAuxWords, "keys and queues fit where the run lengths would be");
 static_assert(kSpTile / kSpThreads == 4, "positions of a thread are handled as two pairs");
 
-__global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
-                                                     const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
-                                                     uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
-                                                     uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile, uint32_t tune_mean_bucket,
-                                                     uint32_t tune_budget, uint32_t tune_max_bucket) {
+// Flags of a tile (`dense_tile`): 0 done here, kTileExhaustive: left to the exhaustive kernel, kTilePairs: left to
+// k_lz77_pairs.  That kernel is this one again for the tiles without runs whose buckets are long (PAIRS_KERNEL, see
+// `grouped` below): with that path compiled in, the common path of this kernel got 12 % slower (60 instead of 40
+// registers, other schedules), and those tiles are few or many by the kind of image, so they are listed and redone.
+constexpr uint8_t kTileExhaustive = 1, kTilePairs = 2;
+template <bool PAIRS_KERNEL>
+__device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                 const uint32_t *__restrict__ sb_first, uint32_t n, const uint32_t tile,
+                                                 uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
+                                                 uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile, uint32_t tune_mean_bucket,
+                                                 uint32_t tune_budget, uint32_t tune_max_bucket) {
   __shared__ __attribute__((aligned(16))) uint32_t px[kSpSources + kMaxLen + 4];
   // Tiles with runs: runlen[i] = pixels equal to pixel i from there on (within the window), 16 bits each.  Tiles without
   // runs use the same memory per wave: the best match so far of the 128 positions the wave is working on and a queue of
@@ -720,12 +728,8 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   __shared__ uint32_t wmin[kSpWaves];
   __shared__ uint32_t s_abort, s_inside, s_sumsq, s_heavy;
   constexpr uint32_t kPerSuper = kSuper / kSpTile;
-  // Workgroups go round-robin to the 8 XCDs, each with its own L2.  Neighbouring tiles share half of their
-  // window, so every XCD takes one contiguous eighth of the tiles: the overlap is then read from its L2, not twice from HBM.
-  const uint32_t per_xcd = gridDim.x / 8;  // the grid is a multiple of 8
-  const uint32_t tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-  if (tile >= ntiles) return;
-  const uint32_t sb = tile / kPerSuper, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t sb = tile / kPerSuper, img = find_image(sb_first, n, sb);
   const uint32_t M = st[img].M, xsize = st[img].xsize, xinv = st[img].xinv;
   const uint32_t a = (tile - sb_first[img] * kPerSuper) * kSpTile;
   if (a >= M) return;
@@ -734,13 +738,14 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   const uint32_t hi = b + kMaxLen - 1 < M ? b + kMaxLen - 1 : M;  // one past the last pixel an extension may read
   const uint32_t W = hi - lo;
   const uint64_t pos0 = imgs[img].pos0;
+  if (PAIRS_KERNEL && dense_tile[(pos0 + a) / kLzTile] != kTilePairs) return;
   const uint32_t *data = pix + pos0;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   VP8L_PHASE_BEGIN();
   for (uint32_t i = tid; i < kSpBuckets / 2; i += kSpThreads) cursor2[i] = 0;
   if (tid == 0) { s_abort = 0; s_inside = 0; s_sumsq = 0; s_heavy = 0; }
   // lo is a multiple of 4 (a and kWindow are) and the pixel array has readable slack past M: 16-byte loads
-  if (st[img].fused) {
+  if (!PAIRS_KERNEL && st[img].fused) {
     // Subtract-green path: the residual is made here from the caller's pixels (vp8l.h:594-597,
     // transform.cpp:88-106) and this tile's part of it is stored for the later stages; k_transform skips the image.
     const uint32_t *argb = imgs[img].argb;  // 16-byte aligned, exactly M pixels
@@ -783,7 +788,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
     if (lane == 0 && inside) atomicAdd(&s_inside, inside);
   }
   __syncthreads();
-  const bool plain = s_inside * 16 < nsrc;
+  const bool plain = PAIRS_KERNEL || s_inside * 16 < nsrc;  // (the tiles of the pairs kernel have been found to be so)
   if (plain) first_of_run = valid;
   if (!plain) {
     // ---- run lengths: a run ends at j when px[j+1] differs or j is the last pixel of the window
@@ -816,19 +821,21 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
     }
   }
   VP8L_PHASE_MARK(1);  // hashes, run starts, run lengths
+  if (!PAIRS_KERNEL) {
 #pragma unroll
-  for (uint32_t k = 0; k < kSpSources / kSpThreads; k++)
-    if ((first_of_run >> k) & 1u) {
-      const uint32_t hb = mixed[k] >> (32 - kSpPosBits);
-      atomicAdd(&cursor2[hb >> 1], 1u << (16 * (hb & 1u)));
-    }
+    for (uint32_t k = 0; k < kSpSources / kSpThreads; k++)
+      if ((first_of_run >> k) & 1u) {
+        const uint32_t hb = mixed[k] >> (32 - kSpPosBits);
+        atomicAdd(&cursor2[hb >> 1], 1u << (16 * (hb & 1u)));
+      }
+  }
   __syncthreads();
   VP8L_PHASE_MARK(2);  // bucket counts
   // exclusive scan of the bucket counts (8 per thread)
   uint32_t c[8], sum = 0, mx = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const uint32_t two = cursor2[tid * 4 + k];
+    const uint32_t two = PAIRS_KERNEL ? 0u : cursor2[tid * 4 + k];
     c[2 * k] = two & 0xffffu;
     c[2 * k + 1] = two >> 16;
   }
@@ -839,9 +846,10 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   if (mx > tune_max_bucket) s_abort = 1;
   if (mx >= kSpHeavyBucket) s_heavy = 1;
   __syncthreads();
-  if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
+  if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; return; }
   uint32_t run = incl - sum;
   for (uint32_t k = 0; k < wave; k++) run += wsum[k];
+  uint32_t entries = 0;  // of all buckets (counted for tiles with a full bucket only)
   if (s_heavy) {
     // Some value is frequent.  Many entries of few values (two-colour noise bundled eight pixels to a word, 16 colours
     // two to a word): every position has dozens of candidates that extend a little, and the exhaustive kernel is
@@ -855,9 +863,8 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
     sq = wave_sum_u32(sq);
     if (lane == 0 && sq) atomicAdd(&s_sumsq, sq);
     __syncthreads();
-    uint32_t entries = 0;
     for (uint32_t k = 0; k < kSpWaves; k++) entries += wsum[k];
-    if (s_sumsq > tune_mean_bucket * entries) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
+    if (s_sumsq > tune_mean_bucket * entries) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; return; }
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -869,17 +876,76 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   // A tile without runs that has a full bucket scatters its sources group by group (a group = the kSpThreads sources
   // of one round, consecutive indices), so that a bucket holds its entries in the order of the groups: a walk can then
   // stop where the groups begin that hold no source of its position (see collect_and_score).
-  const bool grouped = plain && s_heavy;
+  // ... and whose entries share their bucket with kSpPairsMeanBucket others or more on average: below that, walks are
+  // short enough and two more counting sorts do not pay.
+  const bool grouped = PAIRS_KERNEL || (plain && s_heavy && s_sumsq >= kSpPairsMeanBucket * entries);
+  if (!PAIRS_KERNEL && grouped) {
+    if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = kTilePairs;
+    return;
+  }
+  if (!grouped) {
 #pragma unroll
-  for (uint32_t k = 0; k < kSpSources / kSpThreads; k++) {
-    const uint32_t i = k * kSpThreads + tid;
-    if ((first_of_run >> k) & 1u) {
-      const uint32_t hb = mixed[k] >> (32 - kSpPosBits), sh16 = 16 * (hb & 1u);
-      items[(atomicAdd(&cursor2[hb >> 1], 1u << sh16) >> sh16) & 0xffffu] = (mixed[k] << kSpTagShift) | i;
+    for (uint32_t k = 0; k < kSpSources / kSpThreads; k++) {
+      const uint32_t i = k * kSpThreads + tid;
+      if ((first_of_run >> k) & 1u) {
+        const uint32_t hb = mixed[k] >> (32 - kSpPosBits), sh16 = 16 * (hb & 1u);
+        items[(atomicAdd(&cursor2[hb >> 1], 1u << sh16) >> sh16) & 0xffffu] = (mixed[k] << kSpTagShift) | i;
+      }
     }
-    if (grouped && k + 1 < kSpSources / kSpThreads) __syncthreads();
   }
   __syncthreads();
+  // The table of a grouped tile, built by the whole workgroup: on the sources' first two pixels (PAIRS) or on their
+  // first one.  The mix of two pixels is no bijection: an entry whose tag fits is compared with both pixels.
+  auto pair_mix = [](uint32_t mixed_first, uint32_t second) {
+    uint32_t h = mixed_first + second * 0x85EBCA77u;
+    h ^= h >> 15;
+    return h * 0x2C1B3C6Du;
+  };
+  auto build_grouped = [&](auto pairs_tag) {
+    constexpr bool PAIRS = decltype(pairs_tag)::value;
+    for (uint32_t i = tid; i < kSpBuckets / 2; i += kSpThreads) cursor2[i] = 0;
+    uint32_t hs[kSpSources / kSpThreads];
+#pragma unroll
+    for (uint32_t k = 0; k < kSpSources / kSpThreads; k++) hs[k] = PAIRS ? pair_mix(mixed[k], px[k * kSpThreads + tid + 1]) : mixed[k];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kSpSources / kSpThreads; k++)
+      if ((valid >> k) & 1u) {
+        const uint32_t hb = hs[k] >> (32 - kSpPosBits);
+        atomicAdd(&cursor2[hb >> 1], 1u << (16 * (hb & 1u)));
+      }
+    __syncthreads();
+    uint32_t cc[8], total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t two = cursor2[tid * 4 + k];
+      cc[2 * k] = two & 0xffffu;
+      cc[2 * k + 1] = two >> 16;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) total += cc[k];
+    const uint32_t inc = wave_incl_scan_u32(total, (int)lane);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t at = inc - total;
+    for (uint32_t k = 0; k < wave; k++) at += wsum[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t lo16 = at, hi16 = at + cc[2 * k];
+      cursor2[tid * 4 + k] = lo16 | (hi16 << 16);
+      at = hi16 + cc[2 * k + 1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kSpSources / kSpThreads; k++) {  // group by group: a barrier after each round
+      const uint32_t i = k * kSpThreads + tid;
+      if ((valid >> k) & 1u) {
+        const uint32_t hb = hs[k] >> (32 - kSpPosBits), sh16 = 16 * (hb & 1u);
+        items[(atomicAdd(&cursor2[hb >> 1], 1u << sh16) >> sh16) & 0xffffu] = (hs[k] << kSpTagShift) | i;
+      }
+      __syncthreads();
+    }
+  };
   VP8L_PHASE_MARK(3);  // scan of the counts and scatter into the buckets
   // ---- tiles without runs: collect, then score.  A wave walks the buckets of 64 positions at a time and only *collects* the sources that
   // hold the position's value within its window (most walks find none, and a wave that scored them where it found
@@ -889,13 +955,18 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   // (lz77.h:68), which is the order of the keys, so candidates can be scored in any order.  Queue and keys (`mem`: 128
   // keys, 64 queue entries) belong to the wave alone: no workgroup barrier in here, and results are stored as soon as a
   // pair of rounds is done (a tile that gives up later is redone as a whole by the exhaustive kernel).
-  auto collect_and_score = [&](uint32_t *keys, auto grouped_tag) {
+  auto collect_and_score = [&](uint32_t *keys, auto grouped_tag, auto pairs_tag, uint64_t (&open_positions)[4]) -> bool {
     // GROUPED: the buckets hold their entries group by group (above).  The sources of a position lie in the groups from
     // the one of its window's first index to its own, so positions of the tile's first half walk a bucket forwards and
     // stop at the first entry of a later group than their own, the others walk it backwards and stop at the first entry
     // of a group before their window's: 58 % of a bucket on average instead of all of it.  Worth its five barriers and
     // two instructions per step only where buckets are long.
+    // PAIRS: the table is on the sources' first two pixels: every candidate matches for two pixels at least, and the
+    // positions left with a shorter match or none are not stored but returned in `open_positions` (a mask of lanes per
+    // round): their best match is the farthest source of their value, which the table on single pixels will tell.
+    // Returns true when the tile was given up (then the exhaustive kernel redoes it).
     constexpr bool GROUPED = decltype(grouped_tag)::value;
+    constexpr bool PAIRS = decltype(pairs_tag)::value;
     uint32_t *queue = keys + 128;
     uint32_t spent = 0;
 #pragma unroll 1
@@ -953,11 +1024,13 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
 #pragma unroll
       for (uint32_t kk = 0; kk < 2; kk++) {
         const uint32_t ip = ip0 + kk * kSpThreads + lane;
-        uint32_t i = 0, stop = 0, step = 1, tag = 0, span = 0, x1 = 0;
+        uint32_t i = 0, stop = 0, step = 1, tag = 0, span = 0, x0 = 0, x1 = 0;
         uint32_t first_index = 0, indices = 1u << kSpPosBits;  // GROUPED: entries with other indices end the walk
         if (lo + ip < b) {
-          const uint32_t x = px[ip], mxd = x * kSpMul, h = mxd >> (32 - kSpPosBits);
+          const uint32_t x = px[ip];
           x1 = px[ip + 1];
+          x0 = x;
+          const uint32_t mxd = PAIRS ? pair_mix(x * kSpMul, x1) : x * kSpMul, h = mxd >> (32 - kSpPosBits);
           tag = mxd << kSpTagShift;
           stop = cursor[h];
           i = h ? cursor[h - 1] : 0u;
@@ -989,7 +1062,9 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
             } else {
               t = e ^ tag;
               cand = ip - 1 - t < span;
-              if (cand && px[t + 1] != x1) {
+              if (PAIRS) {
+                if (cand && (px[t] != x0 || px[t + 1] != x1)) cand = false;  // another pair with the same mix
+              } else if (cand && px[t + 1] != x1) {
                 const uint32_t k1 = (1u << 11) | (ip - t);
                 one_pixel[kk] = one_pixel[kk] > k1 ? one_pixel[kk] : k1;
                 cand = false;
@@ -1001,27 +1076,107 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
         }
       }
       if (qn) score(qn);
+      uint64_t still_open[2] = {0, 0};
 #pragma unroll
       for (uint32_t kk = 0; kk < 2; kk++) {
         const uint32_t p = lo + ip0 + kk * kSpThreads + lane;
+        bool open = false;
         if (p < b) {
           uint32_t key = keys[kk * 64 + lane];
           key = key > one_pixel[kk] ? key : one_pixel[kk];
           if (p == M - 1) key = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
-          const uint32_t o = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_code_of(xsize, xinv, key & 2047u) << 19)) : 0u;
-          match[pos0 + p] = o;
-          adv[pos0 + p] = (uint8_t)((o & 0xff) ? (o & 0xff) : 1u);
+          open = PAIRS && key < (2u << 11) && p != M - 1;
+          if (!open) {
+            const uint32_t o = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_code_of(xsize, xinv, key & 2047u) << 19)) : 0u;
+            match[pos0 + p] = o;
+            adv[pos0 + p] = (uint8_t)((o & 0xff) ? (o & 0xff) : 1u);
+          }
         }
+        if (PAIRS) still_open[kk] = __ballot(open);
+      }
+      if (PAIRS) {
+        if (pair == 0) { open_positions[0] = still_open[0]; open_positions[1] = still_open[1]; }
+        else { open_positions[2] = still_open[0]; open_positions[3] = still_open[1]; }
       }
       if (__ballot(spent > tune_budget)) {  // too much work for this form: the exhaustive kernel redoes the tile
-        if (lane == 0) dense_tile[(pos0 + a) / kLzTile] = 1;
-        return;
+        if (lane == 0) dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive;
+        return true;
+      }
+    }
+    return false;
+  };
+  // The positions that the table on pairs left open (a mask of lanes per round of the wave): the farthest source of the
+  // position's value among the 1024 before it matches for one pixel and is the best match (lz77.h:68); none: a literal.
+  // 64 open positions at a time walk the table on single pixels; `list` is the wave's own memory.
+  auto farthest_of_value = [&](uint16_t *list, const uint64_t (&open_positions)[4]) {
+    uint32_t count = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < 4; r++) {
+      const uint64_t m = open_positions[r];
+      if ((m >> lane) & 1u) {
+        const uint32_t at = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        list[at] = (uint16_t)(a - lo + (r >> 1) * (2 * kSpThreads) + (r & 1u) * kSpThreads + wave * 64 + lane);
+      }
+      count += (uint32_t)__popcll(m);
+    }
+    wave_sync_lds();
+    for (uint32_t base = 0; base < count; base += 64) {
+      const bool mine = base + lane < count;
+      const uint32_t ip = mine ? list[base + lane] : 0u;
+      uint32_t i = 0, stop = 0, step = 1, tag = 0, span = 0, far = 0;
+      uint32_t first_index = 0, indices = 1u << kSpPosBits;
+      if (mine) {
+        const uint32_t mxd = px[ip] * kSpMul, h = mxd >> (32 - kSpPosBits);
+        tag = mxd << kSpTagShift;
+        stop = cursor[h];
+        i = h ? cursor[h - 1] : 0u;
+        span = ip < kWindow ? ip : kWindow;
+        if (ip < kSpTile) {
+          indices = (ip + kSpThreads - 1) & ~(kSpThreads - 1);
+        } else {
+          first_index = (ip - span) & ~(kSpThreads - 1);
+          const uint32_t beg = i;
+          i = stop - 1;
+          stop = beg - 1;
+          step = ~0u;
+        }
+      }
+      while (__ballot(i != stop)) {
+        if (i != stop) {
+          const uint32_t e = items[i];
+          if ((e & ((1u << kSpPosBits) - 1)) - first_index >= indices) {
+            i = stop;
+          } else {
+            const uint32_t t = e ^ tag;
+            if (ip - 1 - t < span && ip - t > far) far = ip - t;
+            i += step;
+          }
+        }
+      }
+      if (mine) {
+        const uint32_t p = lo + ip;
+        const uint32_t o = far ? (1u | (far << 8) | (dist_code_of(xsize, xinv, far) << 19)) : 0u;
+        match[pos0 + p] = o;
+        adv[pos0 + p] = 1;
       }
     }
   };
   if (plain) {  // keys and queues where the run lengths of other tiles are
-    if (grouped) collect_and_score(aux + wave * kSpWaveAux, std::true_type{});
-    else collect_and_score(aux + wave * kSpWaveAux, std::false_type{});
+    uint64_t open_positions[4] = {0, 0, 0, 0};
+    if constexpr (PAIRS_KERNEL) {
+     if (grouped) {
+      // Full buckets: a few values hold much of the tile, and a walk over all sources of a position's value is long.
+      // Pairs of pixels hardly repeat: the table on pairs finds every match of two pixels and more with short walks,
+      // and only the positions that have none walk the table on single pixels afterwards, 64 to a round.
+      build_grouped(std::true_type{});
+      const bool gave_up = collect_and_score(aux + wave * kSpWaveAux, std::true_type{}, std::true_type{}, open_positions);
+      __syncthreads();  // every wave is done with the table on pairs
+      build_grouped(std::false_type{});
+      if (!gave_up) farthest_of_value(reinterpret_cast<uint16_t *>(aux + wave * kSpWaveAux), open_positions);
+      return;
+     }
+    }
+    (void)collect_and_score(aux + wave * kSpWaveAux, std::false_type{}, std::false_type{}, open_positions);
     return;
   }
   // ---- tiles with runs: candidates are scored where they are found.  (Collecting them first, as above, made these
@@ -1082,7 +1237,7 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   if (over) s_abort = 1;
   __syncthreads();
   VP8L_PHASE_MARK(5);  // waiting for the other waves
-  if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = 1; return; }
+  if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; return; }
 #pragma unroll
   for (uint32_t k = 0; k < kSpTile / kSpThreads; k++) {
     const uint32_t p = a + k * kSpThreads + tid;
@@ -1094,13 +1249,48 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
   VP8L_PHASE_MARK(6);  // results stored
 }
 
+__global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                     const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
+                                                     uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
+                                                     uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile, uint32_t tune_mean_bucket,
+                                                     uint32_t tune_budget, uint32_t tune_max_bucket) {
+  // Workgroups go round-robin to the 8 XCDs, each with its own L2.  Neighbouring tiles share half of their
+  // window, so every XCD takes one contiguous eighth of the tiles: the overlap is then read from its L2, not twice from HBM.
+  const uint32_t per_xcd = gridDim.x / 8;  // the grid is a multiple of 8
+  const uint32_t tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (tile >= ntiles) return;
+  lz77_sparse_tile<false>(imgs, st, sb_first, n, tile, pix, match, adv, dense_tile, tune_mean_bucket, tune_budget, tune_max_bucket);
+}
+
+// The tiles that k_lz77_sparse marked kTilePairs (it has stored their residual already).  Often there are none, and a
+// workgroup per tile that only looks and leaves costs 1.7 ms per 259200 tiles: a fixed grid, each workgroup taking every
+// gridDim.x-th tile.  (Eight waves per SIMD are asked for by name: left alone, the compiler spends 113 registers on the
+// loop and only two workgroups fit a CU.)
+__global__ __launch_bounds__(kSpThreads, 8) void k_lz77_pairs(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                    const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
+                                                    uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
+                                                    uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile, uint32_t tune_mean_bucket,
+                                                    uint32_t tune_budget, uint32_t tune_max_bucket) {
+  // 64 of the workgroup's tiles at a time: every lane looks at one flag, then the marked ones are done one after the other
+  for (uint32_t base = blockIdx.x; base < ntiles; base += 64 * gridDim.x) {
+    const uint32_t mine = base + (threadIdx.x & 63u) * gridDim.x;
+    uint64_t marked = __ballot(mine < ntiles && dense_tile[mine] == kTilePairs);
+    while (marked) {
+      const uint32_t k = (uint32_t)__builtin_ctzll(marked);
+      marked &= marked - 1;
+      lz77_sparse_tile<true>(imgs, st, sb_first, n, base + k * gridDim.x, pix, match, adv, dense_tile, tune_mean_bucket, tune_budget, tune_max_bucket);
+      __syncthreads();  // the tile's shared memory is the next tile's
+    }
+  }
+}
+
 __global__ __launch_bounds__(256, 4) void k_lz77(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                               const uint32_t *__restrict__ sb_first, uint32_t n,
                                               const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                               uint8_t *__restrict__ adv, const uint8_t *__restrict__ dense_tile) {
   constexpr uint32_t kPerSuper = kSuper / kLzBlock;
   // tiles the candidate-list kernel completed are done; it flags the ones it gave up on (tile number = wave number)
-  if (dense_tile && __builtin_amdgcn_readfirstlane((int)dense_tile[blockIdx.x * kLzWaves + (threadIdx.x >> 6)]) == 0) return;
+  if (dense_tile && __builtin_amdgcn_readfirstlane((int)dense_tile[blockIdx.x * kLzWaves + (threadIdx.x >> 6)]) != kTileExhaustive) return;
   const uint32_t blk = blockIdx.x, sb = blk / kPerSuper, img = find_image(sb_first, n, sb);
   const uint32_t M = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[img].M);
   const int lane = threadIdx.x & 63;
@@ -1123,7 +1313,7 @@ __global__ __launch_bounds__(64) void k_lz77_head(const EncImage *__restrict__ i
                                                   uint8_t *__restrict__ adv, const uint8_t *__restrict__ dense_tile) {
   const uint32_t img = blockIdx.x / (kLzHead / kLzHeadPiece);
   if (img >= n) return;
-  if (dense_tile && __builtin_amdgcn_readfirstlane((int)dense_tile[(size_t)sb_first[img] * (kSuper / kLzTile)]) == 0) return;
+  if (dense_tile && __builtin_amdgcn_readfirstlane((int)dense_tile[(size_t)sb_first[img] * (kSuper / kLzTile)]) != kTileExhaustive) return;
   const uint32_t M = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[img].M);
   const uint32_t a = (blockIdx.x % (kLzHead / kLzHeadPiece)) * kLzHeadPiece;
   uint32_t b = a + kLzHeadPiece;
@@ -2021,8 +2211,12 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   }
   mark(2);
   if (match_mode == 0)
+  {
     hipLaunchKernelGGL(k_lz77_sparse, dim3((gsb * (kSuper / kSpTile) + 7) / 8 * 8), dim3(kSpThreads), 0, s, B.imgs, B.st, B.sbf, nl,
                        gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0], g_tune[1], g_tune[2]);
+    hipLaunchKernelGGL(k_lz77_pairs, dim3(std::min<uint32_t>(gsb * (kSuper / kSpTile), kSpPairsGrid)), dim3(kSpThreads), 0, s, B.imgs, B.st, B.sbf, nl,
+                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0], g_tune[1], g_tune[2]);
+  }
   mark(9);  // also when the candidate-list kernel is switched off
   hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,
                      match_mode == 0 ? B.dense : (const uint8_t *)nullptr);
@@ -2356,7 +2550,7 @@ extern "C" long vp8l_encoder_last_dense_tiles(vp8l_encoder *e, long *total_tiles
   for (size_t i = 0; i < e->imgs.size(); i++) {
     if (!e->imgs[i].argb) continue;
     const uint64_t t0 = e->imgs[i].pos0 / kLzTile, nt = ((uint64_t)e->states[i].M + kLzTile - 1) / kLzTile;
-    for (uint64_t t = 0; t < nt; t++) dense += f[t0 + t];
+    for (uint64_t t = 0; t < nt; t++) dense += f[t0 + t] == kTileExhaustive;
     total += (long)nt;
   }
   if (total_tiles) *total_tiles = total;
