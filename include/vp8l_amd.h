@@ -113,13 +113,14 @@ int vp8l_encoder_encode_device(vp8l_encoder *enc, size_t n, const uint32_t *cons
  * (about 20 MB, held by every GPU the library runs on until the process ends) instead of a context's hipMalloc'ed
  * buffers, and the call makes no hipMalloc / hipFree / host allocation.  At most VP8L_NOALLOC_MAX_PIXELS pixels
  * (1920x1080 fits); larger images return VP8L_ERR_NO_MEMORY.
- *   device    < 0 = the current device
+ *   device    < 0 = the current device; >= 0: that device, made current for the length of the call only
  *   stream    a hipStream_t (NULL = the null stream); every kernel of the call is launched on it
  *   d_out     device buffer, 256-byte aligned, out_cap >= vp8l_encode_bound(width, height)
  *   d_result  optional device pointer to two uint64: [0] = status (a vp8l_status, sign-extended), [1] = stream bytes
  *   out_len   optional host pointer.  Non-NULL: the call waits for the stream and returns the image's status with
  *             *out_len set.  NULL: nothing is waited for (the call only launches) and VP8L_OK means "launched".
- * The address of the static array is looked up once per device, by vp8l_init() or else by the first call on the device.
+ * The address of the static array is looked up once per device: by vp8l_init() for the device that is current when it
+ * is called, else by the first call on the device.
  * All calls on one GPU share the array: calls that overlap in time on one GPU (two streams, two threads) race. */
 #define VP8L_NOALLOC_MAX_PIXELS (1u << 21)
 int vp8l_encode_device_noalloc(int device, void *stream, const uint32_t *d_argb, uint32_t width, uint32_t height,

@@ -71,7 +71,39 @@ struct Image {
   std::vector<uint8_t> bytes;  // row-major, (has_alpha ? 4 : 3) bytes per pixel
 };
 
-inline Image read_png_bytes(const std::vector<uint8_t> &file) {
+// Inflates `in` into exactly out.size() bytes.  zlib counts in 32 bits, so both sides are offered in pieces of at most
+// `piece` bytes (a parameter so that a test can force many pieces).  Never Z_FINISH: with less output room than the data
+// needs, zlib turns a call that made progress into Z_BUF_ERROR.  Ends when the output is full, the stream ends, zlib
+// reports a real error, or a call moves neither side.
+inline bool inflate_exactly(const std::vector<uint8_t> &in, std::vector<uint8_t> &out, size_t piece) {
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (inflateInit(&zs) != Z_OK) return false;
+  if (piece == 0 || piece > ((size_t)1 << 30)) piece = (size_t)1 << 30;
+  size_t in_pos = 0, got = 0;
+  bool ok = true;
+  while (got < out.size()) {
+    if (zs.avail_in == 0 && in_pos < in.size()) {
+      const size_t n = std::min(piece, in.size() - in_pos);
+      zs.next_in = const_cast<uint8_t *>(in.data()) + in_pos;
+      zs.avail_in = (uInt)n;
+      in_pos += n;
+    }
+    const size_t room = std::min(piece, out.size() - got);
+    const uInt in_before = zs.avail_in;
+    zs.next_out = out.data() + got;
+    zs.avail_out = (uInt)room;
+    const int rc = inflate(&zs, Z_NO_FLUSH);
+    got += room - zs.avail_out;
+    if (rc == Z_STREAM_END) break;
+    if (rc != Z_OK && rc != Z_BUF_ERROR) { ok = false; break; }
+    if (zs.avail_out == room && zs.avail_in == in_before && in_pos == in.size()) break;  // nothing moved, nothing left to offer
+  }
+  inflateEnd(&zs);
+  return ok && got == out.size();
+}
+
+inline Image read_png_bytes(const std::vector<uint8_t> &file, size_t inflate_piece = (size_t)1 << 30) {
   using namespace detail;
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
   if (file.size() < 8 || memcmp(file.data(), sig, 8) != 0) throw Error{"PNG: bad signature"};
@@ -133,31 +165,7 @@ inline Image read_png_bytes(const std::vector<uint8_t> &file) {
     if (pw && ph) raw_size += ph * (1 + (pw * bits_pp + 7) / 8);
   }
   std::vector<uint8_t> raw(raw_size);
-  {
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (inflateInit(&zs) != Z_OK) throw Error{"PNG: zlib"};
-    // zlib counts in 32 bits: both sides are fed in pieces of at most 1 GiB
-    const size_t piece = (size_t)1 << 30;
-    size_t in_pos = 0, got = 0;
-    int rc = Z_OK;
-    while (rc == Z_OK) {
-      if (zs.avail_in == 0 && in_pos < idat.size()) {
-        const size_t n = std::min(piece, idat.size() - in_pos);
-        zs.next_in = idat.data() + in_pos;
-        zs.avail_in = (uInt)n;
-        in_pos += n;
-      }
-      const size_t room = std::min(piece, raw.size() - got);
-      zs.next_out = raw.data() + got;
-      zs.avail_out = (uInt)room;
-      rc = inflate(&zs, in_pos == idat.size() ? Z_FINISH : Z_NO_FLUSH);
-      got += room - zs.avail_out;
-      if (rc == Z_BUF_ERROR || (got == raw.size() && rc == Z_OK)) break;  // no progress possible, or the image is complete
-    }
-    inflateEnd(&zs);
-    if ((rc != Z_STREAM_END && rc != Z_OK && rc != Z_BUF_ERROR) || got != raw.size()) throw Error{"PNG: bad image data"};
-  }
+  if (!inflate_exactly(idat, raw, inflate_piece)) throw Error{"PNG: bad image data"};
 
   // samples at file depth: channels x uint16 per pixel
   std::vector<uint16_t> smp((size_t)w * h * channels);

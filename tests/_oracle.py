@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 _ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 _REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_parts.so")
+_REF_DRIVER_SO = os.path.join(ORACLE_DIR, "_ref", "libref_driver.so")
 
 ALPHABET = (280, 256, 256, 256, 40)
 
@@ -140,6 +141,54 @@ def ref():
     return _ref
 
 
+_ref_driver = None
+
+REF_CRASHED = -99
+
+
+def ref_driver_available():
+    """Whether the reference's encoder/decoder drivers were compiled (oracle/_ref/libref_driver.so)."""
+    return os.path.exists(_REF_DRIVER_SO)
+
+
+def ref_driver():
+    global _ref_driver
+    if _ref_driver is None:
+        if not os.path.exists(_REF_DRIVER_SO):
+            return None
+        R = C.CDLL(_REF_DRIVER_SO)
+        R.ref_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
+        R.ref_encode.restype = C.c_long
+        R.ref_decode.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32),
+                                 C.POINTER(C.c_uint32)]
+        R.ref_decode.restype = C.c_int
+        _ref_driver = R
+    return _ref_driver
+
+
+def ref_encode(argb, w, h):
+    """The reference's VP8_LOSSLESS_ENCODER (vp8l.h:585-615): (status, stream bytes)."""
+    argb = np.ascontiguousarray(argb, dtype=np.uint32)
+    cap = 8 * argb.size + (1 << 16)
+    buf = np.zeros(cap, dtype=np.uint8)
+    n = ref_driver().ref_encode(argb.ctypes.data if argb.size else None, argb.size, w, h, buf.ctypes.data, cap)
+    if n < 0:
+        return int(n), b""
+    return 0, buf[:n].tobytes()
+
+
+def ref_decode(data, max_pixels=1 << 24):
+    """The reference's VP8_LOSSLESS_DECODER (vp8l.h:330-351) in a forked child:
+    (status, argb | None, w, h); status REF_CRASHED when the child died."""
+    out = np.zeros(max_pixels, dtype=np.uint32)
+    w = C.c_uint32()
+    h = C.c_uint32()
+    rc = ref_driver().ref_decode(bytes(data), len(data), out.ctypes.data, max_pixels, C.byref(w), C.byref(h))
+    if rc != 0:
+        return int(rc), None, 0, 0
+    return 0, out[: w.value * h.value].copy(), w.value, h.value
+
+
 # --------------------------------------------------------------------------- helpers
 def gen_image(mode, w, h, seed=12345, ncolors=200):
     img = np.empty(w * h, dtype=np.uint32)
@@ -262,3 +311,22 @@ def inverse_transform(ttype, argb, w, h, tdata=None, txsize=0, tbits=0):
     rc = lib().ora_inverse_transform(ttype, img.ctypes.data, w, h, None if td is None else td.ctypes.data,
                                      txsize, tbits)
     return rc, img
+
+
+def case_image(desc):
+    """A test image from a small descriptor (shared by the recorded fixtures and their tests):
+    ["gen", mode, w, h, seed] the synthetic generators; ["pal", ncolors, w, h, seed] random palette
+    indices; ["rand", w, h, seed] noise."""
+    kind = desc[0]
+    if kind == "gen":
+        _, mode, w, h, seed = desc
+        return gen_image(mode, w, h, seed, 200), w, h
+    if kind == "pal":
+        _, ncol, w, h, seed = desc
+        rng = np.random.default_rng(seed)
+        pal = rng.integers(0, 1 << 32, size=ncol, dtype=np.uint32)
+        return pal[rng.integers(0, ncol, size=w * h)], w, h
+    if kind == "rand":
+        _, w, h, seed = desc
+        return np.random.default_rng(seed).integers(0, 1 << 32, size=w * h, dtype=np.uint32), w, h
+    raise ValueError(desc)

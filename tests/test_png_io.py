@@ -18,9 +18,9 @@ DUMP = os.path.join(ROOT, "tools", "png_dump")
 pytestmark = pytest.mark.skipif(not os.path.exists(DUMP), reason="tools/png_dump not built")
 
 
-def dump(path, tmp_path):
+def dump(path, tmp_path, piece=None):
     out = str(tmp_path / "out.argb")
-    r = subprocess.run([DUMP, path, out], capture_output=True, text=True)
+    r = subprocess.run([DUMP, path, out] + ([str(piece)] if piece else []), capture_output=True, text=True)
     if r.returncode != 0:
         return None, r.stderr
     raw = open(out, "rb").read()
@@ -199,6 +199,41 @@ def test_writer_read_back_by_pillow(tmp_path):
     assert im.mode == "RGB" and im.size == (w, h)       # save2png drops alpha (webp.h:90-95,122-125)
     rgb = np.asarray(im).astype(np.uint32)
     assert np.array_equal((rgb[..., 0] << 16) | (rgb[..., 1] << 8) | rgb[..., 2], argb & 0xFFFFFF)
+
+
+def test_image_data_inflated_in_many_pieces(tmp_path):
+    """zlib counts in 32 bits, so the reader offers input and output room in pieces (1 GiB); a piece of a few bytes
+    forces the many-pieces path on a small file: same pixels, and damaged or short data is still refused."""
+    rng = np.random.default_rng(8)
+    w, h = 61, 47
+    smp = rng.integers(0, 256, size=(h, w, 4))
+    for interlace in (False, True):
+        path = str(tmp_path / ("pieces%d.png" % interlace))
+        png = make_png(smp, 6, 8, interlace)
+        open(path, "wb").write(png)
+        whole, err = dump(path, tmp_path)
+        assert whole is not None, err
+        for piece in (1, 7, 100, 4096):
+            got, err = dump(path, tmp_path, piece)
+            assert got is not None, (piece, err)
+            assert np.array_equal(got, whole), piece
+    # incompressible data: output room runs out many times with input still pending
+    path = str(tmp_path / "stored.png")
+    raw = b"".join(b"\0" + rng.integers(0, 256, size=w * 4, dtype=np.uint8).tobytes() for _ in range(h))
+    png = (b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0))
+           + _chunk(b"IDAT", zlib.compress(raw, 0)) + _chunk(b"IEND", b""))
+    open(path, "wb").write(png)
+    whole, err = dump(path, tmp_path)
+    assert whole is not None, err
+    for piece in (3, 1000):
+        got, err = dump(path, tmp_path, piece)
+        assert got is not None and np.array_equal(got, whole), (piece, err)
+    short = (b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h + 1, 8, 6, 0, 0, 0))
+             + _chunk(b"IDAT", zlib.compress(raw, 0)) + _chunk(b"IEND", b""))
+    open(path, "wb").write(short)
+    for piece in (None, 5):
+        got, err = dump(path, tmp_path, piece)
+        assert got is None
 
 
 def test_broken_files_are_refused(tmp_path):

@@ -142,6 +142,11 @@ def encode(argb, width, height, predictor_bits=0, cross_color_bits=0, standard=F
     # the C ABI cannot know the buffer's size (the C++ mirror checks the same, webp.hpp): a short array would be read past its end
     if a is not None and a.size and max(int(width), int(height)) <= 16384 and a.size < int(width) * int(height):
         raise Vp8lError(-1, "vp8l_encode (array holds %d pixels, %d x %d needs %d)" % (a.size, width, height, int(width) * int(height)))
+    # each option has its own field of the flags word: a value beyond its range would spill into the next field
+    for name, v, hi in (("predictor_bits", predictor_bits, 9), ("cross_color_bits", cross_color_bits, 9), ("cache_bits", cache_bits, 11),
+                        ("meta_bits", meta_bits, 9)):
+        if not 0 <= int(v) <= hi:
+            raise Vp8lError(-10, "vp8l_encode (%s = %d, allowed 0..%d)" % (name, int(v), hi))
     out = C.c_void_p()
     n = C.c_size_t()
     rc = lib().vp8l_encode(a.ctypes.data if a is not None and a.size else None, width, height, C.byref(out), C.byref(n), int(predictor_bits) | (int(cross_color_bits) << 4) | (0x100 if standard else 0) | (int(cache_bits) << 12) | (int(meta_bits) << 16))

@@ -282,7 +282,7 @@ extern "C" int vp8l_init(void) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::string(prop.gcnArchName).rfind("gfx950", 0) == 0) usable++;
   }
-  if (usable > 0) noalloc_setup_all_devices();
+  if (usable > 0) noalloc_setup_current_device();
   return usable > 0 ? usable : VP8L_ERR_NO_DEVICE;
 }
 
@@ -500,8 +500,18 @@ int run_on_devices(const int *devices, size_t ndevices, const std::vector<uint64
     rcs[d] = guarded([&] { return first[d + 1] > first[d] ? part(devices[d], first[d], first[d + 1] - first[d]) : (int)VP8L_OK; });
     if (rcs[d] != VP8L_OK) texts[d] = last_error_slot();
   };
-  for (size_t d = 1; d < ndevices; d++) threads.emplace_back(body, d);
+  // a thread that cannot be started (std::system_error) must not unwind past joinable threads: its part runs here instead
+  std::vector<size_t> inline_parts;
+  threads.reserve(ndevices);
+  for (size_t d = 1; d < ndevices; d++) {
+    try {
+      threads.emplace_back(body, d);
+    } catch (const std::exception &) {
+      inline_parts.push_back(d);
+    }
+  }
   body(0);
+  for (size_t d : inline_parts) body(d);
   for (auto &t : threads) t.join();
   for (size_t d = 0; d < ndevices; d++)
     if (rcs[d] != VP8L_OK) { last_error_slot() = texts[d]; return rcs[d]; }

@@ -2640,17 +2640,15 @@ int noalloc_workspace(int device, uint8_t **out) {
 }
 }  // namespace
 
-// Called by vp8l_init(): looks the workspace address up on every usable device so that the entry point's first call
-// on a device does nothing but launch.  Leaves the current device as it was.
-void noalloc_setup_all_devices() {
-  int count = 0, before = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || hipGetDevice(&before) != hipSuccess) { (void)hipGetLastError(); return; }
-  for (int d = 0; d < count && d < kNaMaxDevices; d++) {
-    if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
-    uint8_t *p = nullptr;
-    (void)noalloc_workspace(d, &p);
-  }
-  (void)hipSetDevice(before);
+// Called by vp8l_init(): looks the workspace address up on the calling thread's current device, so that the entry
+// point's first call there does nothing but launch.  Other devices are looked up by their own first call: asking on a
+// device creates a context and loads the code object there (with the workspace), which a process that uses one GPU of
+// eight should not pay eight times.
+void noalloc_setup_current_device() {
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return; }
+  uint8_t *p = nullptr;
+  (void)noalloc_workspace(device, &p);
 }
 
 // Writes the one-image tables a batch call uploads from the host.
@@ -2687,10 +2685,20 @@ extern "C" int vp8l_encode_device_noalloc(int device, void *stream, const uint32
     return VP8L_ERR_NO_MEMORY;
   }
   if (out_cap < vp8l_encode_bound(width, height)) return VP8L_ERR_NO_MEMORY;
+  // a device >= 0 is made current for the length of this call only (the caller's own choice comes back on every path)
+  struct DeviceScope {
+    int before = -1;
+    ~DeviceScope() { if (before >= 0) (void)hipSetDevice(before); }
+  } scope;
   if (device < 0) {
     if (!hip_ok(hipGetDevice(&device), "hipGetDevice")) return VP8L_ERR_NO_DEVICE;
-  } else if (!hip_ok(hipSetDevice(device), "hipSetDevice")) {
-    return VP8L_ERR_NO_DEVICE;
+  } else {
+    int current = -1;
+    if (!hip_ok(hipGetDevice(&current), "hipGetDevice")) return VP8L_ERR_NO_DEVICE;
+    if (current != device) {
+      if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return VP8L_ERR_NO_DEVICE;
+      scope.before = current;
+    }
   }
   uint8_t *ws = nullptr;
   int rc = noalloc_workspace(device, &ws);

@@ -38,7 +38,7 @@ int guarded(Body body) {
 }
 
 // Looks up the address of the static no-allocation workspace on every device (vp8l_encode.hip).
-void noalloc_setup_all_devices();
+void noalloc_setup_current_device();
 
 // Grow-only device allocation (the contexts keep their workspace between calls).
 struct DeviceBuffer {
