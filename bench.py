@@ -529,8 +529,8 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # not under a launcher: start one rank per GPU ourselves, before anything here touches a GPU
-        have = torch.cuda.device_count()   # counting devices does not initialise the GPU
-        if have < args.gpus and not SHARE_GPU:
+        have = sharding.visible_gpu_count()   # from the driver's topology files: no call into the GPU runtime here
+        if have is not None and have < args.gpus and not SHARE_GPU:
             sys.exit("bench.py: --gpus %d but only %d device(s) visible" % (args.gpus, have))
         rc, out0 = sharding.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
         sys.stdout.write(out0)

@@ -6,8 +6,10 @@
 //     webp/utils/utils.h (array<T> :12-107), webp/utils/bit_writer.h (BitWriter :20-92)
 //     webp/exception/exception.h
 // compiles against this header instead; all codec work runs on the GPU behind the C ABI.
-// Header-only; link with libvp8l_amd.so.  PNG input/output (read_png webp.cpp:16-117, save2png
-// webp.h:83-144) is not part of the codec path and is not provided.
+// Header-only; link with libvp8l_amd.so.  WebP_DECODER::save2png (webp.h:83-144) writes its PNG
+// through png_io.hpp (zlib instead of libpng: a program that calls it links with -lz); read_png
+// is part of the reference's command line tool (webp.cpp:16-117), not of this interface, and
+// has its counterpart in png_io.hpp as well.
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -18,6 +20,7 @@
 #include <vector>
 
 #include "../vp8l_amd.h"
+#include "png_io.hpp"
 
 namespace webp {
 
@@ -40,6 +43,7 @@ WEBP_AMD_EXC(UnsupportedVP8, "VP8 is unsupported");
 WEBP_AMD_EXC(InvalidVP8L, "Invalid VP8L");
 WEBP_AMD_EXC(InvalidHuffman, "Invalid format");
 WEBP_AMD_EXC(InvalidARGBImage, "Invalid ARGB image");
+WEBP_AMD_EXC(PNGError, "PNG error");
 #undef WEBP_AMD_EXC
 class TooBigCodeLength : public Exception {  // exception.h:121-131 prints instead of setting a message
  public:
@@ -91,6 +95,13 @@ class array {
 };
 typedef array<uint32_t> pixel_array;
 typedef array<uint8_t> byte_array;
+
+// webp/utils/utils.cpp:55-73: pointers to the bytes of a 0xAARRGGBB pixel in memory (little endian), which the
+// reference's read_png writes through (webp.cpp:99-108).
+inline uint8_t *ALPHA(const uint32_t &argb) { return (uint8_t *)(&argb) + 3; }
+inline uint8_t *RED(const uint32_t &argb) { return (uint8_t *)(&argb) + 2; }
+inline uint8_t *GREEN(const uint32_t &argb) { return (uint8_t *)(&argb) + 1; }
+inline uint8_t *BLUE(const uint32_t &argb) { return (uint8_t *)(&argb); }
 
 // The encoder's output as the reference exposes it (bit_writer.h:65-90): size() bytes,
 // save2file() APPENDS to the file.
@@ -168,7 +179,7 @@ class WebP_ENCODER {
   }
 };
 
-// webp/webp.h:20-149 without save2png: the decoded pixels are exposed instead.
+// webp/webp.h:20-149; the decoded pixels are exposed as well (argb()).
 class WebP_DECODER {
   utils::pixel_array m_argb_image;
   uint32_t m_image_width, m_image_height;
@@ -193,6 +204,18 @@ class WebP_DECODER {
     vp8l::VP8_LOSSLESS_DECODER decoder(buf.data() + 16, vp8_len, m_argb_image);
     m_image_width = decoder.image_width();
     m_image_height = decoder.image_height();
+  }
+  // webp.h:83-144: 8-bit RGB, not interlaced, alpha dropped.  A file that cannot be opened is a
+  // FileOperationException, any other failure a PNGError, as there.
+  void save2png(const std::string &file_name) {
+    FILE *fp = fopen(file_name.c_str(), "wb");
+    if (!fp) throw exception::FileOperationException();
+    fclose(fp);
+    try {
+      png_io::write_png(file_name, m_argb_image.data(), m_image_width, m_image_height);
+    } catch (const png_io::Error &) {
+      throw exception::PNGError();
+    }
   }
   const utils::pixel_array &argb() const { return m_argb_image; }
   uint32_t image_width() const { return m_image_width; }

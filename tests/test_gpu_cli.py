@@ -14,14 +14,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "tools", "webp_")
 
 
-def run(*args):
-    return subprocess.run([CLI, *args], capture_output=True, text=True, timeout=120)
+# The reference's own webp.cpp, compiled unchanged against include/compat/webp/webp.h (the mirror) and linked with the
+# GPU library by oracle/Makefile where the reference checkout exists; the binary travels to the GPU box.
+REF_MAIN = os.path.join(ROOT, "oracle", "_ref", "webp_ref_main")
+TOOLS = [CLI] + ([REF_MAIN] if os.path.exists(REF_MAIN) else [])
 
 
+def run(*args, tool=CLI):
+    return subprocess.run([tool, *args], capture_output=True, text=True, timeout=120)
+
+
+@pytest.mark.parametrize("tool", TOOLS, ids=[os.path.basename(t) for t in TOOLS])
 @pytest.mark.parametrize("kind", ["RGB", "RGBA", "P"])
-def test_encode_decode_files(tmp_path, kind):
+def test_encode_decode_files(tmp_path, kind, tool):
     from PIL import Image
-    assert os.path.exists(CLI), "tools/webp_ not built"
+    assert os.path.exists(tool), "tools/webp_ not built"
     w, h = 200, 77
     argb = O.gen_image(3 if kind != "P" else 5, w, h, 9, 40)
     rgb = np.stack([(argb >> 16) & 255, (argb >> 8) & 255, argb & 255], axis=-1).astype(np.uint8).reshape(h, w, 3)
@@ -41,7 +48,7 @@ def test_encode_decode_files(tmp_path, kind):
         want = (np.uint32(0xFF000000) | (q[..., 0] << 16) | (q[..., 1] << 8) | q[..., 2]).reshape(-1)
     src, mid, dst = str(tmp_path / "in.png"), str(tmp_path / "out.webp"), str(tmp_path / "back.png")
     im.save(src)
-    r = run("-e", src, mid)
+    r = run("-e", src, mid, tool=tool)
     assert r.returncode == 0, r.stdout + r.stderr
     rc, stream = O.encode(np.ascontiguousarray(want, dtype=np.uint32), w, h)
     assert rc == 0
@@ -49,7 +56,7 @@ def test_encode_decode_files(tmp_path, kind):
     assert data[:4] == b"RIFF" and data[8:16] == b"WEBPVP8L"            # webp.h:167-173
     assert struct.unpack("<I", data[4:8])[0] == len(stream) + 8
     assert data[16:] == stream
-    r = run("-d", mid, dst)
+    r = run("-d", mid, dst, tool=tool)
     assert r.returncode == 0, r.stdout + r.stderr
     back = np.asarray(Image.open(dst)).astype(np.uint32)
     assert np.array_equal(((back[..., 0] << 16) | (back[..., 1] << 8) | back[..., 2]).reshape(-1), want & 0xFFFFFF)

@@ -26,9 +26,9 @@ def expected_image(w, h, mode):
 @pytest.mark.parametrize("w,h,mode", [(40, 30, 0), (33, 7, 1), (1, 1, 0)])
 def test_cpp_shim_roundtrip_and_container(tmp_path, w, h, mode):
     assert os.path.exists(EXE), "build first (__graft_entry__.build())"
-    webp, raw = str(tmp_path / "o.webp"), str(tmp_path / "o.vp8l")
+    webp, raw, png = str(tmp_path / "o.webp"), str(tmp_path / "o.vp8l"), str(tmp_path / "o.png")
     # torch's bundled HIP runtime is not involved here: a plain C++ process on the system runtime
-    r = subprocess.run([EXE, str(w), str(h), str(mode), webp, raw], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([EXE, str(w), str(h), str(mode), webp, raw, png], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     stream = open(raw, "rb").read()
     rc, ref = O.encode(expected_image(w, h, mode), w, h)
@@ -37,3 +37,9 @@ def test_cpp_shim_roundtrip_and_container(tmp_path, w, h, mode):
     assert blob[:4] == b"RIFF" and blob[8:16] == b"WEBPVP8L"
     assert struct.unpack("<I", blob[4:8])[0] == len(stream) + 8
     assert blob[16:] == stream
+    # save2png (webp.h:83-144): 8-bit RGB, alpha dropped
+    from PIL import Image
+    im = Image.open(png)
+    assert im.mode == "RGB" and im.size == (w, h)
+    rgb = np.asarray(im).astype(np.uint32).reshape(-1, 3)
+    assert np.array_equal((rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2], expected_image(w, h, mode) & 0xFFFFFF)

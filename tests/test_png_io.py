@@ -164,6 +164,67 @@ def test_every_png_kind(tmp_path, ctype, depth, interlace, with_trns):
     assert np.array_equal(got, expected_argb(rgba, has_alpha))
 
 
+REF_CLI = os.path.join(ROOT, "oracle", "_ref", "webp_ref_cli")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CLI), reason="oracle/_ref/webp_ref_cli not built (no reference checkout here)")
+def test_reference_tool_reads_the_same_pixels(tmp_path):
+    """The reference's own command line tool (webp.cpp with libpng, compiled in place by oracle/Makefile) encodes every
+    PNG kind; the pixels inside its .webp (read back with the oracle's decoder) must be the pixels png_io gives, and its
+    -d must write the RGB that png_io's writer writes."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    from PIL import Image
+    rng = np.random.default_rng(77)
+    n = 0
+    for ctype, depth in CASES:
+        for interlace in (False, True):
+            for with_trns in (False, True):
+                if with_trns and ctype in (4, 6):
+                    continue
+                # widths that fill whole groups of bundled palette indices: the reference's own decoder overruns its
+                # rows otherwise (transform.h:70-86) and its -d then crashes on few-colour pictures
+                w, h = 8 * int(rng.integers(1, 4)), int(rng.integers(2, 19))
+                ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+                plte = trns = None
+                if ctype == 3:
+                    ncol = 1 << depth
+                    plte = rng.integers(0, 256, size=ncol * 3).tolist()
+                    smp = rng.integers(0, ncol, size=(h, w, 1))
+                    if with_trns:
+                        trns = rng.integers(0, 256, size=max(1, ncol // 2)).tolist()
+                else:
+                    # few levels, so that no channel uses all 256 values evenly (the stream the reference cannot read back)
+                    smp = rng.integers(0, min(1 << depth, 23), size=(h, w, ch)) * (1 if depth < 16 else 2311)
+                    if with_trns:
+                        v = smp[0, 0]
+                        trns = b"".join(struct.pack(">H", int(x)) for x in v)
+                path = str(tmp_path / "k.png")
+                open(path, "wb").write(make_png(smp, ctype, depth, interlace, plte, trns))
+                mine, err = dump(path, tmp_path)
+                assert mine is not None, err
+                out = str(tmp_path / "k.webp")
+                if os.path.exists(out):
+                    os.remove(out)
+                r = subprocess.run([REF_CLI, "-e", path, out], capture_output=True, text=True)
+                assert r.returncode == 0
+                blob = open(out, "rb").read()
+                assert blob[:4] == b"RIFF" and blob[8:16] == b"WEBPVP8L"
+                rc, dec, dw, dh = O.decode(blob[16:])
+                assert rc == 0 and (dw, dh) == (w, h), (ctype, depth, interlace, with_trns)
+                assert np.array_equal(dec.reshape(h, w), mine), (ctype, depth, interlace, with_trns)
+                # and back: the reference's save2png against this repository's writer
+                ref_png, my_png, raw = str(tmp_path / "r.png"), str(tmp_path / "m.png"), str(tmp_path / "m.argb")
+                assert subprocess.run([REF_CLI, "-d", out, ref_png], capture_output=True).returncode == 0
+                open(raw, "wb").write(struct.pack("<II", w, h) + mine.astype(np.uint32).tobytes())
+                assert subprocess.run([DUMP, "-w", raw, my_png]).returncode == 0
+                a, b = Image.open(ref_png), Image.open(my_png)
+                assert a.mode == b.mode == "RGB" and np.array_equal(np.asarray(a), np.asarray(b))
+                n += 1
+    assert n > 40
+
+
 def test_against_pillow(tmp_path):
     from PIL import Image
     rng = np.random.default_rng(5)

@@ -86,3 +86,39 @@ def test_launcher_starts_one_child_per_rank():
     assert "noise" not in out
     rc, out = sharding.launch_ranks(2, [sys.executable, "-c", "import os, sys; sys.exit(3 if os.environ['RANK'] == '1' else 0)"], timeout=60)
     assert rc == 3
+
+
+def test_visible_gpu_count_reads_the_topology_without_the_runtime(tmp_path):
+    root = tmp_path / "nodes"
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):
+        d = root / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    assert sharding.visible_gpu_count(str(root), {}) == 3
+    assert sharding.visible_gpu_count(str(root), {"HIP_VISIBLE_DEVICES": "0,2"}) == 2
+    assert sharding.visible_gpu_count(str(root), {"ROCR_VISIBLE_DEVICES": "1", "HIP_VISIBLE_DEVICES": "0,1"}) == 1
+    assert sharding.visible_gpu_count(str(root), {"CUDA_VISIBLE_DEVICES": ""}) == 0
+    assert sharding.visible_gpu_count(str(tmp_path / "missing"), {}) is None
+
+
+def test_bench_refuses_more_ranks_than_gpus_before_starting_any(tmp_path):
+    """`bench.py --gpus N` with N beyond the visible devices ends with an error from the launcher parent itself: no
+    child is started (a marker the children would write stays absent) and the GPU runtime is never asked."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    topo = tmp_path / "nodes" / "0"
+    topo.mkdir(parents=True)
+    (topo / "properties").write_text("simd_count 1024\n")
+    have = 1
+    marker = tmp_path / "child_started"
+    code = ("import os,sys\n"
+            "if 'WORLD_SIZE' in os.environ: open(%r,'w').close()\n"
+            "sys.argv=['bench.py','--gpus',%r]\n"
+            "import runpy; runpy.run_path(%r, run_name='__main__')\n") % (str(marker), str(have + 1), os.path.join(root, "bench.py"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VP8L_BENCH_SHARE_GPU")}
+    env["VP8L_KFD_TOPOLOGY"] = str(tmp_path / "nodes")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "device(s) visible" in r.stderr
+    assert not marker.exists()

@@ -60,7 +60,7 @@ Verdict scan(int argc, char **argv, Request &req) {
 
 void decode_to_png(const std::string &webp_path, const std::string &png_path) {
   webp::WebP_DECODER decoded(webp_path);
-  webp::png_io::write_png(png_path, decoded.argb().data(), decoded.image_width(), decoded.image_height());
+  decoded.save2png(png_path);  // webp.cpp:175-176
 }
 
 void encode_from_png(const std::string &png_path, const std::string &webp_path) {

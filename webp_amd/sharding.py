@@ -37,6 +37,34 @@ def global_throughput(pixels_local, seconds_local, device=None):
     return int(px.item()), float(sec.item())
 
 
+def visible_gpu_count(kfd_root=None, environ=None):
+    """Number of GPUs this process could use, found WITHOUT any HIP call (a launcher that forks one rank per GPU must
+    not touch the GPU runtime itself): the driver's topology lists every node with its `simd_count` (0 for CPU nodes),
+    and the visible-devices variables of the runtime (a comma-separated list each) can only narrow that down.  None
+    when the topology cannot be read at all (the answer is then unknown, which is not the same as zero)."""
+    import glob
+    import os
+    env = os.environ if environ is None else environ
+    if kfd_root is None:  # VP8L_KFD_TOPOLOGY: another directory of the same layout (tests)
+        kfd_root = env.get("VP8L_KFD_TOPOLOGY", "/sys/class/kfd/kfd/topology/nodes")
+    count = 0
+    if not os.path.isdir(kfd_root):
+        return None
+    for path in glob.glob(os.path.join(kfd_root, "*", "properties")):
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            count += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if var in env:
+            listed = [t for t in env[var].split(",") if t.strip() != ""]
+            count = min(count, len(listed))
+    return count
+
+
 def launch_ranks(n_ranks, argv, master_port=None, env_extra=None, timeout=None):
     """Starts `argv` n_ranks times as child processes, one per GPU of this node, with the environment torch.distributed
     expects (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT), waits for all of them and returns
