@@ -115,3 +115,18 @@ def test_one_shot_entry_point_with_flags():
     for bad in (1, 10, 16):
         with pytest.raises(webp_amd.Vp8lError):
             webp_amd.encode(img, 96, 64, predictor_bits=bad)
+
+
+def test_streams_the_reference_decoder_read():
+    """tests/golden/gpu_ext_streams.json (tools/pin_gpu_streams.py): sha256 of the streams this encoder wrote for a fixed
+    set of images and options (predictor, cross-colour, colour cache, meta codes, alone and together) which the REFERENCE's
+    own compiled decoder (vp8l.h:330-345) turned back into the images.  The encoder must still write exactly those."""
+    import hashlib
+    import json
+    import os
+    cases = json.load(open(os.path.join(O.ROOT, "tests", "golden", "gpu_ext_streams.json")))
+    assert len(cases) >= 50
+    for ent in cases:
+        img, w, h = O.case_image(ent["image"])
+        data = webp_amd.encode(img, w, h, **ent["options"])
+        assert len(data) == ent["bytes"] and hashlib.sha256(data).hexdigest() == ent["sha256"], (ent["image"], ent["options"])
