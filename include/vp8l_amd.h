@@ -126,9 +126,10 @@ int vp8l_encoder_encode_device(vp8l_encoder *enc, size_t n, const uint32_t *cons
 int vp8l_encode_device_noalloc(int device, void *stream, const uint32_t *d_argb, uint32_t width, uint32_t height,
                                uint8_t *d_out, size_t out_cap, uint64_t *d_result, size_t *out_len);
 
-/* Options.  VP8L_OPT_MATCH_SEARCH: 0 (default) = candidate-list match search with the exhaustive
- * search as fallback for tiles with heavy duplication; 1 = exhaustive search everywhere.  Both give
- * identical streams; the option exists for verification and measurement. */
+/* Options.  VP8L_OPT_MATCH_SEARCH: 0 (default) = candidate-list match search; tiles with heavy duplication go on to the
+ * forms made for them (one frequent value; pairs of pixels) and last to the exhaustive search; 1 = exhaustive search
+ * everywhere; 2 = the candidate lists refuse every tile, so the forms behind them see all of them.  All give identical
+ * streams; the option exists for verification and measurement. */
 enum { VP8L_OPT_MATCH_SEARCH = 1, VP8L_OPT_PREDICTOR_BITS = 2, VP8L_OPT_CROSS_COLOR_BITS = 3, VP8L_OPT_STANDARD = 4,
        VP8L_OPT_CACHE_BITS = 5, VP8L_OPT_META_BITS = 6, VP8L_OPT_META_GROUPS = 7 };
 /* VP8L_OPT_PREDICTOR_BITS: 0 (default) = the reference encoder's output (subtract green or colour indexing only,
@@ -158,6 +159,10 @@ enum { VP8L_OPT_MATCH_SEARCH = 1, VP8L_OPT_PREDICTOR_BITS = 2, VP8L_OPT_CROSS_CO
 int vp8l_encoder_set_option(vp8l_encoder *enc, int option, int value);
 /* Number of 2048-position tiles of the last call that needed the exhaustive search (and the total). */
 long vp8l_encoder_last_dense_tiles(vp8l_encoder *enc, long *total_tiles);
+/* How the tiles of the last call were searched: counts8[k] = tiles with flag k (0 candidate lists, 1 exhaustive search,
+ * 2 lists on pairs of pixels, 4 lists around one frequent value; every form gives the same matches).  Returns the total.
+ * No counterpart in the reference (lz77.h:28-93 has one form): a measurement aid. */
+long vp8l_encoder_last_tile_kinds(vp8l_encoder *enc, long *counts8);
 
 /* Stage outputs of the LAST encode call on this context, for parity checks of the intermediate
  * planes (copied to host memory).  what: */

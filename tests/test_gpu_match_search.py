@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def run(img, w, h, exhaustive):
     import torch
     enc = webp_amd.Encoder()
-    enc.set_exhaustive_search(exhaustive)
+    enc.set_match_search(int(exhaustive))
     d_in = torch.from_numpy(img.view(np.int32)).cuda()
     cap = enc.bound(w, h)
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
@@ -25,17 +25,28 @@ def run(img, w, h, exhaustive):
     m = enc.fetch_stage(0, webp_amd.STAGE_MATCH)
     res = enc.fetch_stage(0, webp_amd.STAGE_RESIDUAL)
     dense, total = enc.last_dense_tiles()
+    run.kinds = enc.last_tile_kinds()
     data = bytes(d_out[int(off[0]): int(off[0]) + int(lens[0])].cpu().numpy())
     enc.close()
     return m, res, dense, total, data
 
 
-def check(img, w, h, expect=None):
-    m0, res, dense, total, s0 = run(img, w, h, False)
-    m1, _, dense1, total1, s1 = run(img, w, h, True)
+def check(img, w, h, expect=None, behind_the_lists=False):
+    """behind_the_lists: a third run in which the candidate lists refuse every tile, so that the forms behind them
+    (frequent value, then exhaustive) search all of it; its tile kinds are left in run.kinds."""
+    m1, _, dense1, total1, s1 = run(img, w, h, 1)
+    m0, res, dense, total, s0 = run(img, w, h, 0)
+    kinds0 = run.kinds
     assert dense1 == total1 == total
     ln, ds = O.lz77_best_all(res)
-    for m in (m0, m1):
+    results = [m0, m1]
+    if behind_the_lists:
+        m2, _, _, _, s2 = run(img, w, h, 2)
+        assert s2 == s0
+        results.append(m2)
+    else:
+        run.kinds = kinds0
+    for m in results:
         assert np.array_equal(m & 0xFF, ln)
         assert np.array_equal(np.where(ln > 0, (m >> 8) & 0x7FF, 0), ds)
     assert s0 == s1
@@ -209,3 +220,58 @@ def test_few_frequent_values_without_runs(seed):
     dense, total = check(img, 15000, 1)
     assert dense < total, (dense, total)
     check(img, 125, 120)
+
+
+def _frequent_value_image(rng, n, v0, mean_run, alphabet, pairs=0.1):
+    """Runs of v0 (geometric lengths) with single pixels -- sometimes two or three -- of other values between them."""
+    vals = rng.integers(0, 1 << 24, size=alphabet, dtype=np.uint32) | np.uint32(0xFF000000)
+    out = []
+    total = 0
+    while total < n:
+        r = int(rng.geometric(1.0 / mean_run))
+        out.append(np.full(r, v0, dtype=np.uint32))
+        k = 1 + int(rng.random() < pairs) + int(rng.random() < pairs / 3)
+        o = vals[rng.integers(0, alphabet, size=k)]
+        if rng.random() < 0.05:
+            o[:] = o[0]  # a short run of another value
+        out.append(o)
+        total += r + k
+    return np.concatenate(out)[:n]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_one_frequent_value(seed):
+    # What the predictor leaves of flat pictures: one value in runs, other pixels singly between them.  Such tiles leave
+    # the candidate lists and are searched around the frequent value (k_lz77_dominant), not exhaustively.
+    rng = np.random.default_rng(700 + seed)
+    n = 2048 * 5 + int(rng.integers(0, 2048))
+    v0 = np.uint32(0xFF000000) if seed % 2 == 0 else np.uint32(0xFF000000 | int(rng.integers(0, 1 << 24)))
+    mean_run = float([6, 2.5, 15, 40, 6, 9, 3, 80][seed])
+    alphabet = int([6, 3, 40, 1000, 300, 2, 12, 5][seed])
+    img = _frequent_value_image(rng, n, v0, mean_run, alphabet)
+    # matches that go on behind a run: copies of stretches that hold several runs
+    for _ in range(12):
+        s = int(rng.integers(1100, n - 400)); d = int(rng.integers(1, 1025)); l = int(rng.integers(5, 300))
+        img[s:s + l] = img[s - d:s - d + l].copy()
+    if seed == 3:
+        img[4000:4200] = v0       # a run of 128 and more
+        img[6000:7300] = v0       # longer than the window
+    if seed == 4:
+        img[-50:] = v0            # the image ends inside a run
+    img[200:600] = (np.arange(400, dtype=np.uint32) * np.uint32(0x010305)) | np.uint32(0xFF000000)  # more than 256 colours: no palette
+    check(img, n, 1, behind_the_lists=True)
+    if alphabet >= 40:  # (with few other values the anchors' lists outgrow their pool and the tile goes on to the exhaustive search)
+        assert run.kinds.get("frequent_value", 0) >= 3, run.kinds
+    w = 125
+    check(img[: (n // w) * w], w, n // w, behind_the_lists=True)
+
+
+def test_frequent_value_tiles_next_to_others():
+    rng = np.random.default_rng(801)
+    n = 2048 * 8
+    img = rng.integers(0, 1 << 24, size=n, dtype=np.uint32) | np.uint32(0xFF000000)
+    img[3000:9000] = _frequent_value_image(rng, 6000, np.uint32(0xFF000000), 7.0, 200)
+    img[9000:11000] = np.where(rng.random(2000) < 0.5, np.uint32(0xFF101010), np.uint32(0xFF202020))  # no frequent value: exhaustive
+    img[12000:14500] = _frequent_value_image(rng, 2500, np.uint32(0xFF7F7F7F), 4.0, 60)
+    check(img, n, 1, behind_the_lists=True)
+    assert run.kinds.get("frequent_value", 0) >= 2 and run.kinds.get("exhaustive", 0) >= 1, run.kinds

@@ -86,6 +86,8 @@ def lib():
         L.vp8l_encoder_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.vp8l_encoder_last_dense_tiles.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
         L.vp8l_encoder_last_dense_tiles.restype = C.c_long
+        L.vp8l_encoder_last_tile_kinds.argtypes = [C.c_void_p, C.c_void_p]
+        L.vp8l_encoder_last_tile_kinds.restype = C.c_long
         L.vp8l_encoder_last_device_seconds.argtypes = [C.c_void_p]
         L.vp8l_encoder_last_device_seconds.restype = C.c_double
         L.vp8l_encoder_last_stage_seconds.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -114,7 +116,7 @@ EXPORTED_SYMBOLS = (
     "vp8l_encoder_encode_device", "vp8l_encoder_fetch_stage", "vp8l_decoder_create", "vp8l_decoder_destroy",
     "vp8l_decoder_decode_device", "vp8l_encoder_last_device_seconds", "vp8l_encoder_last_stage_seconds",
     "vp8l_decoder_last_device_seconds", "vp8l_generate_device", "vp8l_encoder_set_option",
-    "vp8l_encoder_last_dense_tiles", "vp8l_decoder_set_option",
+    "vp8l_encoder_last_dense_tiles", "vp8l_encoder_last_tile_kinds", "vp8l_decoder_set_option",
     "vp8l_decoder_last_whole_device_streams",
     "vp8l_decoder_last_scout_streams", "vp8l_encode_device_noalloc", "vp8l_encode_batch_devices", "vp8l_decode_batch_devices",
 )
@@ -320,6 +322,12 @@ class Encoder:
         if rc != OK:
             raise Vp8lError(rc, "vp8l_encoder_set_option")
 
+    def set_match_search(self, mode):
+        """0 (default): candidate lists first; 1: exhaustive everywhere; 2: the candidate lists refuse every tile (same matches)."""
+        rc = lib().vp8l_encoder_set_option(self._h, 1, int(mode))
+        if rc != OK:
+            raise Vp8lError(rc, "vp8l_encoder_set_option")
+
     def set_predictor_bits(self, bits):
         """0 (default): the reference encoder's output.  2..9: add the predictor transform, tiles of 2**bits."""
         rc = lib().vp8l_encoder_set_option(self._h, 2, int(bits))
@@ -358,6 +366,15 @@ class Encoder:
         if dense < 0:
             raise Vp8lError(int(dense), "vp8l_encoder_last_dense_tiles")
         return int(dense), int(total.value)
+
+    def last_tile_kinds(self):
+        """{kind: tiles} of the last call: how each 2048-position tile was searched (same matches whichever way)."""
+        buf = (C.c_long * 8)()
+        total = lib().vp8l_encoder_last_tile_kinds(self._h, buf)
+        if total < 0:
+            raise Vp8lError(int(total), "vp8l_encoder_last_tile_kinds")
+        names = {0: "lists", 1: "exhaustive", 2: "pairs", 4: "frequent_value", 5: "grams"}
+        return {names.get(k, "flag%d" % k): int(buf[k]) for k in range(8) if buf[k]}
 
     def last_stage_seconds(self):
         buf = (C.c_double * 9)()

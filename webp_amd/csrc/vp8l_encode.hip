@@ -1284,6 +1284,10 @@ __global__ __launch_bounds__(kSpThreads, 8) void k_lz77_pairs(const EncImage *__
   }
 }
 
+}  // namespace vp8l
+#include "vp8l_encode_dense.h"
+namespace vp8l {
+
 __global__ __launch_bounds__(256, 4) void k_lz77(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                               const uint32_t *__restrict__ sb_first, uint32_t n,
                                               const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
@@ -2133,7 +2137,7 @@ struct vp8l_encoder {
   // workspace (grown on demand)
   DeviceBuffer d_imgs, d_state, d_sbfirst, d_gsets, d_pix, d_match, d_flags, d_histo, d_tables, d_sx, d_entry,
       d_unit_bits, d_unit_off, d_dense, d_group_bits, d_adv, d_pix2, d_modes, d_elems;
-  int match_mode = 0;  // 0 = candidate lists with exhaustive fallback, 1 = exhaustive only
+  int match_mode = 0;  // 0 = candidate lists with the other forms behind them, 1 = exhaustive only, 2 = the candidate lists give up on every tile (verification of what comes behind them)
   const uint32_t *last_pix = nullptr;  // coded pixels of the last call (for fetch_stage)
   bool last_pred = false;
   bool last_cross = false;
@@ -2153,12 +2157,12 @@ struct vp8l_encoder {
   double stage_seconds[9] = {};
 };
 
-// Heuristics of the candidate-list kernel (when a tile goes to the exhaustive kernel instead); VP8L_TUNE="mean_bucket,budget,max_bucket"
-// overrides them for measurements.
-static uint32_t g_tune[3] = {kSpMaxMeanBucket, kSpBudget, kSpMaxBucket};
+// Heuristics of the candidate-list kernel (when a tile goes to the exhaustive kernel instead); VP8L_TUNE="mean_bucket,budget,max_bucket,dense"
+// overrides them for measurements (dense: bit 0 = k_lz77_dominant runs; every setting gives the same matches).
+static uint32_t g_tune[4] = {kSpMaxMeanBucket, kSpBudget, kSpMaxBucket, 1};
 static const bool g_tune_read = [] {
   const char *v = getenv("VP8L_TUNE");
-  if (v) sscanf(v, "%u,%u,%u", &g_tune[0], &g_tune[1], &g_tune[2]);
+  if (v) sscanf(v, "%u,%u,%u,%u", &g_tune[0], &g_tune[1], &g_tune[2], &g_tune[3]);
   return true;
 }();
 
@@ -2186,6 +2190,9 @@ struct EncBuffers {
 static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl, uint32_t sb_total, uint32_t pred, uint32_t cross,
                                  int match_mode, uint8_t *d_out, hipEvent_t *ev, uint32_t standard = 0, const ExtArgs *extp = nullptr,
                                  uint32_t meta_bits = 0) {
+  // match_mode 2: the candidate lists refuse every tile (no bucket may hold anything), so that the forms behind them see all tiles
+  const uint32_t tune_max_bucket = match_mode == 2 ? 0u : g_tune[2];
+  if (match_mode == 2) match_mode = 0;
   bool h = true;
   h = h && hip_ok(hipMemsetAsync(B.st, 0, nl * sizeof(EncState), s), "clear state");
   h = h && hip_ok(hipMemsetAsync(B.gsets, 0xff, (size_t)nl * kSetSlots * sizeof(unsigned long long), s), "clear sets");
@@ -2213,10 +2220,13 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   if (match_mode == 0)
   {
     hipLaunchKernelGGL(k_lz77_sparse, dim3((gsb * (kSuper / kSpTile) + 7) / 8 * 8), dim3(kSpThreads), 0, s, B.imgs, B.st, B.sbf, nl,
-                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0], g_tune[1], g_tune[2]);
+                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0], g_tune[1], tune_max_bucket);
     hipLaunchKernelGGL(k_lz77_pairs, dim3(std::min<uint32_t>(gsb * (kSuper / kSpTile), kSpPairsGrid)), dim3(kSpThreads), 0, s, B.imgs, B.st, B.sbf, nl,
-                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0], g_tune[1], g_tune[2]);
+                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0], g_tune[1], tune_max_bucket);
   }
+  if (match_mode == 0 && g_tune[3])
+    hipLaunchKernelGGL(k_lz77_dominant, dim3(std::min<uint32_t>(gsb * (kSuper / kSpTile), kDmGrid)), dim3(kDmThreads), 0, s, B.imgs, B.st, B.sbf, nl,
+                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense);
   mark(9);  // also when the candidate-list kernel is switched off
   hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,
                      match_mode == 0 ? B.dense : (const uint8_t *)nullptr);
@@ -2527,7 +2537,7 @@ extern "C" double vp8l_encoder_last_device_seconds(const vp8l_encoder *e) { retu
 extern "C" int vp8l_encoder_set_option(vp8l_encoder *e, int option, int value) {
   if (!e) return VP8L_ERR_BAD_ARGUMENT;
   std::lock_guard<std::mutex> lock(e->mu);
-  if (option == VP8L_OPT_MATCH_SEARCH && (value == 0 || value == 1)) { e->match_mode = value; return VP8L_OK; }
+  if (option == VP8L_OPT_MATCH_SEARCH && value >= 0 && value <= 2) { e->match_mode = value; return VP8L_OK; }
   if (option == VP8L_OPT_PREDICTOR_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->pred_bits = value; return VP8L_OK; }
   if (option == VP8L_OPT_CROSS_COLOR_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->cross_bits = value; return VP8L_OK; }
   if (option == VP8L_OPT_STANDARD && (value == 0 || value == 1)) { e->standard = value != 0; return VP8L_OK; }
@@ -2554,7 +2564,28 @@ extern "C" long vp8l_encoder_last_dense_tiles(vp8l_encoder *e, long *total_tiles
     total += (long)nt;
   }
   if (total_tiles) *total_tiles = total;
-  return e->match_mode == 0 ? dense : total;
+  return e->match_mode != 1 ? dense : total;
+}
+
+// How the tiles of the last call were searched: counts[flag] for the tile flags 0..7 (0 candidate lists, 1 exhaustive,
+// 2 pairs of pixels, 4 frequent value); tiles that hold pixels only.  Returns the number of such tiles.
+extern "C" long vp8l_encoder_last_tile_kinds(vp8l_encoder *e, long *counts8) {
+  if (!e || !counts8) return VP8L_ERR_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lock(e->mu);
+  for (int k = 0; k < 8; k++) counts8[k] = 0;
+  if (e->sb_first.empty()) return 0;
+  if (!hip_ok(hipSetDevice(e->device), "hipSetDevice")) return VP8L_ERR_HIP;
+  const size_t ntiles = (size_t)e->sb_first.back() * (kSuper / kLzTile);
+  std::vector<uint8_t> f(ntiles);
+  if (!hip_ok(hipMemcpy(f.data(), e->d_dense.ptr, ntiles, hipMemcpyDeviceToHost), "fetch tile flags")) return VP8L_ERR_HIP;
+  long total = 0;
+  for (size_t i = 0; i < e->imgs.size(); i++) {
+    if (!e->imgs[i].argb) continue;
+    const uint64_t t0 = e->imgs[i].pos0 / kLzTile, nt = ((uint64_t)e->states[i].M + kLzTile - 1) / kLzTile;
+    for (uint64_t t = 0; t < nt; t++) counts8[f[t0 + t] & 7]++;
+    total += (long)nt;
+  }
+  return total;
 }
 
 extern "C" int vp8l_encoder_last_stage_seconds(const vp8l_encoder *e, double *seconds, int cap) {
@@ -2735,6 +2766,16 @@ extern "C" int vp8l_encode_device_noalloc(int device, void *stream, const uint32
   if (!hip_ok(hipStreamSynchronize(s), "encode (no allocation)")) return VP8L_ERR_HIP;
   *out_len = (size_t)host_result[1];
   return (int)(int64_t)host_result[0];
+}
+
+// Measurement aid: why k_lz77_dominant left tiles to the exhaustive kernel since the last call (then cleared); see g_dm_reason.
+extern "C" int vp8l_debug_dominant_reasons(unsigned int *out4) {
+  if (!out4) return VP8L_ERR_BAD_ARGUMENT;
+  if (!hip_ok(hipDeviceSynchronize(), "sync")) return VP8L_ERR_HIP;
+  if (!hip_ok(hipMemcpyFromSymbol(out4, HIP_SYMBOL(vp8l::g_dm_reason), 4 * sizeof(unsigned int)), "read reasons")) return VP8L_ERR_HIP;
+  unsigned int zero[4] = {};
+  if (!hip_ok(hipMemcpyToSymbol(HIP_SYMBOL(vp8l::g_dm_reason), zero, sizeof(zero)), "clear reasons")) return VP8L_ERR_HIP;
+  return VP8L_OK;
 }
 
 #ifdef VP8L_PHASE_TIMING

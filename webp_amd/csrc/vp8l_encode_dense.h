@@ -1,0 +1,535 @@
+// vp8l_encode_dense.h -- exact match search (LZ77<uint32_t>::pack, lz77.h:51-72) for tiles that the candidate lists of
+// k_lz77_sparse give up on, before the exhaustive kernel has to take them.  Included by vp8l_encode.hip.
+//
+// k_lz77_dominant: tiles in which ONE value holds most of the pixels (predictor residuals of flat or smooth pictures:
+// zeros in runs, single other pixels between them).  The candidate lists fail there because every run of the frequent
+// value v0 is a source for every position inside such a run (150 runs in a window, two candidates each).  For a position
+// p inside a run of v0 with F pixels of v0 from p on and the pixel y != v0 behind them (at p' = p + F):
+//   * a source q of value v0 with Z(q) pixels of v0 from q on matches for min(Z(q), F) pixels when Z(q) != F, so its
+//     length is min(Z(q), F, d): over the runs of v0 in the window that is a question about run lengths alone --
+//     the first run (farthest) whose part inside the window is at least F long gives F, else the longest gives its
+//     length; within p's own run the farthest source gives min(F, its distance).  Answered from the list of v0's runs
+//     in position order with maxima over groups of eight.
+//   * Z(q) == F (aligned): the match goes on behind the run iff the source's next pixel is y too, i.e. the source is
+//     q = c - F for an occurrence c of y with at least F pixels of v0 in front of it, and its length is
+//     F + lcp(c, p') -- the same for every position of the run but for F.  So every run's successor pixel p' ("anchor")
+//     lists the occurrences c of y among the 1024 before it that follow a pixel of v0, each with the number of v0
+//     pixels in front of it and lcp(c, p'), once; the run's positions only look through that list.
+// Every other position (15 % of such tiles) is searched as k_lz77_sparse does it for tiles with runs (first pixel of
+// every source run of its value and the aligned one), with v0's runs left out of the buckets; an anchor is such a
+// position, and the lcp its own search needs is the lcp its list needs.  These positions ("queries") are few, but their
+// buckets differ in length by a factor of twenty, and a thread per query left the workgroup waiting for its longest
+// walk: so all (query, bucket entry) visits of a tile are numbered through, every thread takes an equal stretch of them,
+// and what survives the walk (same value, among the 1024 before the query) is scored where it is found; the scored
+// pairs, in the order of the queries, are the anchors' lists.
+// Results are identical to the exhaustive kernel's (tests/test_gpu_match_search.py, per position against the oracle).
+#pragma once
+
+namespace vp8l {
+
+constexpr uint32_t kDmThreads = 512;
+constexpr uint32_t kDmWaves = kDmThreads / 64;
+constexpr uint32_t kDmTile = kLzTile;
+constexpr uint32_t kDmMaxW = kWindow + kDmTile + kMaxLen;  // the 1024 before the tile, the tile, 127 of look-ahead (+1)
+constexpr uint32_t kDmSeg = 7;                             // window pixels per thread in the segment pass
+constexpr uint32_t kDmMaxStarts = 1024;                    // run starts of other values a window may hold
+constexpr uint32_t kDmMaxRuns = kDmMaxStarts + 2;          // runs of v0 in a window: something else stands between two of them
+constexpr uint32_t kDmSub = 512;                           // positions of a tile that are searched together (a stretch)
+constexpr uint32_t kDmPool = 3072;                         // scored (query, source) pairs of a tile
+constexpr uint32_t kDmMaxVisits = kDmThreads * 64;         // bucket entries all queries of a tile may have to look at
+constexpr uint32_t kDmGrid = 2048;                         // workgroups (two fit a CU)
+constexpr uint8_t kTileDoneDominant = 4;                   // tile flag: searched by k_lz77_dominant
+static_assert(kDmThreads * kDmSeg >= kDmMaxW, "segment pass covers the window");
+static_assert(kDmMaxW <= (1u << kSpPosBits), "window indices fit an entry");
+
+// Why k_lz77_dominant left tiles to the exhaustive kernel, counted since the last vp8l_debug_dominant_reasons() call:
+// [0] no frequent value, [1] too many run starts of other values, [2] too many bucket entries to look at, [3] too many pairs
+__device__ unsigned int g_dm_reason[4];
+
+struct DmShared {
+  uint32_t px[kDmMaxW + 4];
+  uint32_t pool[kDmPool];           // the anchors' lists of a stretch, in the order of the queries: source index | v0 pixels in front of it << 12 | lcp << 19
+  uint32_t keys[kDmSub + 2];        // per query of the stretch: its best match so far, length << 11 | distance
+  uint32_t cursor2[kSpBuckets / 2]; // bucket ends, 16 bits each
+  uint32_t items[kDmMaxStarts];     // run starts of the other values: tag | index
+  uint32_t qcnt2[(kDmSub + 4) / 2]; // per query of the stretch: entries of its list, 16 bits each (added to by LDS atomics)
+  uint16_t runlen[kDmMaxW];         // pixels equal to pixel i from there on (within the window)
+  uint16_t zr[kDmMaxW];             // index of the first run of v0 that ends behind pixel i
+  uint16_t rs[kDmMaxRuns], re[kDmMaxRuns];  // runs of v0: first pixel, one past the last
+  uint16_t qof[kDmMaxRuns];         // per run of v0 whose anchor is a position of the tile: the anchor's number in `others`
+  uint16_t grp[kDmMaxRuns / 8 + 1]; // per 8 runs: longest (capped at 255) << 3 | which one first
+  uint16_t others[kDmTile + 2];     // window indices of the tile's positions of other values, in order
+  uint16_t qbeg[kDmSub + 2];        // per query of the stretch: where its bucket begins in items
+  uint16_t qps[kDmSub + 4];         // per query of the stretch: bucket entries of the queries before it (and the total behind the last)
+  uint16_t qoff[kDmSub + 4];        // per query of the stretch: where its list begins in pool
+  uint8_t len8[kDmMaxRuns];         // run lengths capped at 255
+  uint32_t wsum[kDmWaves], wsum2[kDmWaves], wsum3[kDmWaves], wmin[kDmWaves];
+};
+
+__device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                   const uint32_t *__restrict__ sb_first, uint32_t n, const uint32_t tile,
+                                                   const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
+                                                   uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
+  constexpr uint32_t kPerSuper = kSuper / kDmTile;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t sb = tile / kPerSuper, img = find_image(sb_first, n, sb);
+  const uint32_t M = st[img].M, xsize = st[img].xsize, xinv = st[img].xinv;
+  const uint32_t a = (tile - sb_first[img] * kPerSuper) * kDmTile;
+  if (a >= M) return;
+  const uint32_t b = a + kDmTile < M ? a + kDmTile : M;
+  const uint32_t lo = a > kWindow ? a - kWindow : 0;
+  const uint32_t hi = b + kMaxLen - 1 < M ? b + kMaxLen - 1 : M;
+  const uint32_t W = hi - lo;
+  const uint64_t pos0 = imgs[img].pos0;
+  const uint32_t *data = pix + pos0;
+  uint32_t *px = S.px;
+  for (uint32_t i = tid; i < kSpBuckets / 2; i += kDmThreads) S.cursor2[i] = 0;
+  for (uint32_t i = tid * 4; i < W; i += kDmThreads * 4) *reinterpret_cast<uint4 *>(&px[i]) = *reinterpret_cast<const uint4 *>(data + lo + i);
+  __syncthreads();
+
+  // ---- the frequent value
+  const uint32_t s0 = tid * kDmSeg;
+  uint32_t v[kDmSeg + 1];
+#pragma unroll
+  for (uint32_t j = 0; j <= kDmSeg; j++) v[j] = s0 + j < W ? px[s0 + j] : 0u;
+  const uint32_t prev = s0 > 0 && s0 - 1 < W ? px[s0 - 1] : 0u;
+  // the commonest among 64 samples of the window (every wave finds it for itself, with the same result)
+  uint32_t v0;
+  {
+    const uint32_t smp = px[(2 * lane + 1) * W / 128];
+    uint32_t votes = 0;
+#pragma unroll
+    for (int k = 0; k < 64; k++) votes += (uint32_t)__builtin_amdgcn_readlane((int)smp, k) == smp ? 1u : 0u;
+    uint32_t best = (votes << 6) | (63u - lane);  // most votes, the first lane among equals
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t other = (uint32_t)__shfl_xor((int)best, o, 64);
+      best = other > best ? other : best;
+    }
+    if ((best >> 6) < 6) {  // no value holds a tenth of the samples: the tile stays with the exhaustive kernel
+      if (tid == 0) atomicAdd(&g_dm_reason[0], 1u);
+      return;
+    }
+    v0 = (uint32_t)__shfl((int)smp, (int)(63u - (best & 63u)), 64);
+  }
+
+  // ---- segment pass: run lengths of all values, the runs of v0 in order, the other values' run starts into buckets
+  uint32_t ends = 0, ends0 = 0, starts0 = 0, other_start = 0, mine_other = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < kDmSeg; j++) {
+    const uint32_t i = s0 + j;
+    if (i < W) {
+      const bool last = i == W - 1 || v[j] != v[j + 1];
+      const uint32_t before = j ? v[j - 1] : prev;
+      const bool first = i == 0 || before != v[j];
+      if (last) ends |= 1u << j;
+      if (v[j] == v0) {
+        if (last) ends0 |= 1u << j;
+        if (first) starts0 |= 1u << j;
+      } else {
+        if (first) other_start |= 1u << j;
+        if (i >= a - lo && i < b - lo) mine_other |= 1u << j;
+      }
+    }
+  }
+  {  // run lengths: nearest run end at or behind every pixel (suffix minimum over the threads' first ends)
+    const uint32_t firstb = ends ? s0 + (uint32_t)__builtin_ctz(ends) : 0xffffu;
+    uint32_t m = firstb;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t other = (uint32_t)__shfl_down((int)m, o, 64);
+      if (lane + (uint32_t)o < 64) m = other < m ? other : m;
+    }
+    if (lane == 0) S.wmin[wave] = m;
+    uint32_t after = (uint32_t)__shfl_down((int)m, 1, 64);
+    if (lane == 63) after = 0xffffu;
+    // counts for the three scans: ends of v0's runs, run starts of other values, the tile's positions of other values
+    const uint32_t c_e = (uint32_t)__popc(ends0), c_o = (uint32_t)__popc(other_start), c_m = (uint32_t)__popc(mine_other);
+    const uint32_t i_e = wave_incl_scan_u32(c_e, (int)lane), i_o = wave_incl_scan_u32(c_o, (int)lane), i_m = wave_incl_scan_u32(c_m, (int)lane);
+    if (lane == 63) { S.wsum[wave] = i_e; S.wsum2[wave] = i_o; S.wsum3[wave] = i_m; }
+    __syncthreads();
+    {  // too many runs of other values for the buckets (and then, perhaps, of v0 for its run list): not this kernel's tile
+      uint32_t starts = 0;
+      for (uint32_t w = 0; w < kDmWaves; w++) starts += S.wsum2[w];
+      if (starts > kDmMaxStarts) {  // (the same in every thread)
+        if (tid == 0) atomicAdd(&g_dm_reason[1], 1u);
+        return;
+      }
+    }
+    for (uint32_t w = wave + 1; w < kDmWaves; w++) after = S.wmin[w] < after ? S.wmin[w] : after;
+    uint32_t end = after;
+#pragma unroll
+    for (int j = (int)kDmSeg - 1; j >= 0; j--) {
+      if ((ends >> j) & 1u) end = s0 + (uint32_t)j;
+      if (s0 + (uint32_t)j < W) S.runlen[s0 + j] = (uint16_t)(end - (s0 + j) + 1);
+    }
+    uint32_t base_e = i_e - c_e, base_m = i_m - c_m;
+    for (uint32_t w = 0; w < wave; w++) { base_e += S.wsum[w]; base_m += S.wsum3[w]; }
+    // run k of v0 = the k-th to end; its start has seen k ends before it as well (runs do not nest)
+#pragma unroll
+    for (uint32_t j = 0; j < kDmSeg; j++) {
+      const uint32_t i = s0 + j;
+      if (i < W) {
+        const uint32_t k = base_e + (uint32_t)__popc(ends0 & ((1u << j) - 1u));
+        S.zr[i] = (uint16_t)k;
+        if ((starts0 >> j) & 1u) S.rs[k] = (uint16_t)i;
+        if ((ends0 >> j) & 1u) S.re[k] = (uint16_t)(i + 1);
+        if ((mine_other >> j) & 1u) {
+          const uint32_t qi = base_m + (uint32_t)__popc(mine_other & ((1u << j) - 1u));
+          S.others[qi] = (uint16_t)i;
+          if (i > 0 && (j ? v[j - 1] : prev) == v0) S.qof[k - 1] = (uint16_t)qi;  // the run that ends in front of it is run k - 1
+        }
+      }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kDmSeg; j++)
+      if ((other_start >> j) & 1u) {
+        const uint32_t hb = (v[j] * kSpMul) >> (32 - kSpPosBits);
+        atomicAdd(&S.cursor2[hb >> 1], 1u << (16 * (hb & 1u)));
+      }
+  }
+  __syncthreads();
+  uint32_t R = 0, n_other_starts = 0, n_mine = 0;
+  for (uint32_t w = 0; w < kDmWaves; w++) { R += S.wsum[w]; n_other_starts += S.wsum2[w]; n_mine += S.wsum3[w]; }
+  // exclusive scan of the bucket counts (8 per thread), then the scatter; afterwards cursor[h] = end of bucket h
+  {
+    uint32_t c[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t two = S.cursor2[tid * 4 + k];
+      c[2 * k] = two & 0xffffu;
+      c[2 * k + 1] = two >> 16;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += c[k];
+    const uint32_t incl = wave_incl_scan_u32(sum, (int)lane);
+    __syncthreads();  // everyone has read the totals of the scans above
+    if (lane == 63) S.wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (uint32_t w = 0; w < wave; w++) run += S.wsum[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t lo16 = run, hi16 = run + c[2 * k];
+      S.cursor2[tid * 4 + k] = lo16 | (hi16 << 16);
+      run = hi16 + c[2 * k + 1];
+    }
+  }
+  for (uint32_t r = tid; r < R; r += kDmThreads) {
+    const uint32_t l = (uint32_t)S.re[r] - S.rs[r];
+    S.len8[r] = (uint8_t)(l < 255 ? l : 255);
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < kDmSeg; j++)
+    if ((other_start >> j) & 1u) {
+      const uint32_t mx = v[j] * kSpMul, hb = mx >> (32 - kSpPosBits), sh16 = 16 * (hb & 1u);
+      S.items[(atomicAdd(&S.cursor2[hb >> 1], 1u << sh16) >> sh16) & 0xffffu] = (mx << kSpTagShift) | (s0 + j);
+    }
+  for (uint32_t g = tid; g * 8 < R; g += kDmThreads) {
+    uint32_t best = 0, at = 0;
+    for (uint32_t k = 0; k < 8 && g * 8 + k < R; k++) {
+      const uint32_t l = S.len8[g * 8 + k];
+      if (l > best) { best = l; at = k; }
+    }
+    S.grp[g] = (uint16_t)((best << 3) | at);
+  }
+  __syncthreads();
+  const uint16_t *cursor = reinterpret_cast<const uint16_t *>(S.cursor2);
+  const uint16_t *qcnt = reinterpret_cast<const uint16_t *>(S.qcnt2);
+  const uint32_t ia = a - lo, ib = b - lo;
+
+  // lcp of the pixels from q and from ip on (q < ip), by whole runs, at most `cap` (ip + cap <= W)
+  auto lcp_runs = [&](uint32_t q, uint32_t ip, uint32_t cap) {
+    uint32_t l = 0;
+    do {
+      const uint32_t rq = S.runlen[q + l], rp = S.runlen[ip + l];
+      l += rq < rp ? rq : rp;
+    } while (l < cap && px[q + l] == px[ip + l]);
+    return l < cap ? l : cap;
+  };
+
+  // ---- the tile in stretches of kDmSub positions: first the queries of the stretch (its positions of other values, in
+  // order, and behind them the anchor of the run that holds the stretch's last pixel, if that anchor lies behind the
+  // stretch: its list is needed, its own match is not), then the stretch's positions inside runs of v0.
+  auto first_query_at = [&](uint32_t index) {  // number of queries (tile positions of other values) in front of window index `index`
+    uint32_t l = 0, h = n_mine;
+    while (l < h) {
+      const uint32_t mid = (l + h) >> 1;
+      if (S.others[mid] < index) l = mid + 1; else h = mid;
+    }
+    return l;
+  };
+  for (uint32_t sa = ia; sa < ib; sa += kDmSub) {
+    const uint32_t sb_ = sa + kDmSub < ib ? sa + kDmSub : ib;
+    const uint32_t qlo = first_query_at(sa), nS = first_query_at(sb_) - qlo;
+    uint32_t nR = nS, extra_ip = 0;
+    if (px[sb_ - 1] == v0) {
+      const uint32_t c0 = S.re[S.zr[sb_ - 1]];
+      if (c0 < W) { extra_ip = c0; nR++; }
+    }
+    auto query_index = [&](uint32_t qi) -> uint32_t { return qi < nS ? S.others[qlo + qi] : extra_ip; };
+    {  // per query: its bucket, and the numbering of all bucket entries the queries will look at (two queries per thread)
+      uint32_t sz[2], sum = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t qi = tid * 2 + k;
+        sz[k] = 0;
+        if (qi < nR) {
+          const uint32_t h = (px[query_index(qi)] * kSpMul) >> (32 - kSpPosBits);
+          const uint32_t beg = h ? cursor[h - 1] : 0u;
+          S.qbeg[qi] = (uint16_t)beg;
+          sz[k] = cursor[h] - beg;
+          S.keys[qi] = 0;
+        }
+        sum += sz[k];
+      }
+      for (uint32_t i = tid; i < (kDmSub + 4) / 2; i += kDmThreads) S.qcnt2[i] = 0;
+      const uint32_t incl = wave_incl_scan_u32(sum, (int)lane);
+      if (lane == 63) S.wsum[wave] = incl;
+      __syncthreads();
+      uint32_t at = incl - sum, total = 0;
+      for (uint32_t w = 0; w < kDmWaves; w++) { if (w < wave) at += S.wsum[w]; total += S.wsum[w]; }
+      if (total > kDmMaxVisits) {  // (every thread sees the same total) too much to look at: the exhaustive kernel's tile
+        if (tid == 0) atomicAdd(&g_dm_reason[2], 1u);
+        return;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t qi = tid * 2 + k;
+        if (qi <= nR) S.qps[qi] = (uint16_t)at;  // qps[nR] = the total
+        at += sz[k];
+      }
+    }
+    static_assert(kDmThreads * 2 >= kDmSub + 2 && kDmMaxVisits < 65536, "query scan");
+    __syncthreads();
+    const uint32_t T = S.qps[nR];
+    const uint32_t K = (T + kDmThreads - 1) / kDmThreads;  // visits per thread, at most 64
+    const uint32_t w0 = tid * K < T ? tid * K : T, w1 = w0 + K < T ? w0 + K : T;
+    // the walk: which of this thread's visits find a source of the query's value among the 1024 before it (`hit`), and
+    // which of those belong in the query's list: the query is an anchor and the source follows a pixel of v0 (`keep`)
+    uint64_t hit = 0, keep = 0;
+    uint32_t q_first = 0;
+    if (w0 < w1) {
+      uint32_t lo_q = 0, hi_q = nR;  // largest qi with qps[qi] <= w0
+      while (hi_q - lo_q > 1) {
+        const uint32_t mid = (lo_q + hi_q) >> 1;
+        if (S.qps[mid] <= w0) lo_q = mid; else hi_q = mid;
+      }
+      q_first = lo_q;
+    }
+    {
+      uint32_t qi = q_first, next = 0, ip = 0, tag = 0, base = 0, local = 0;
+      bool fresh = true, anchor = false;
+      for (uint32_t w = w0; w < w1; w++) {
+        if (fresh || w >= next) {
+          if (!fresh && local) { atomicAdd(&S.qcnt2[qi >> 1], local << (16 * (qi & 1u))); local = 0; }
+          while (S.qps[qi + 1] <= w) qi++;
+          next = S.qps[qi + 1];
+          ip = query_index(qi);
+          tag = (px[ip] * kSpMul) << kSpTagShift;
+          base = (uint32_t)S.qbeg[qi] - S.qps[qi];
+          anchor = ip > 0 && px[ip - 1] == v0;
+          fresh = false;
+        }
+        const uint32_t it = S.items[base + w], s = it & ((1u << kSpPosBits) - 1);
+        if ((it ^ tag) >> kSpPosBits || s >= ip || s + kWindow < ip) continue;
+        const bool listed = anchor && s > 0 && px[s - 1] == v0;
+        if (qi < nS || listed) hit |= 1ull << (w - w0);
+        if (listed) { keep |= 1ull << (w - w0); local++; }
+      }
+      if (local) atomicAdd(&S.qcnt2[qi >> 1], local << (16 * (qi & 1u)));
+    }
+    // where every thread's list entries go (the order of the visits is the order of the queries), and where every query's begin
+    uint32_t my_off = 0;
+    {
+      const uint32_t c = (uint32_t)__popcll(keep);
+      const uint32_t incl = wave_incl_scan_u32(c, (int)lane);
+      if (lane == 63) S.wsum2[wave] = incl;
+      __syncthreads();  // the counts per query are complete, too
+      uint32_t total = 0;
+      my_off = incl - c;
+      for (uint32_t w = 0; w < kDmWaves; w++) { if (w < wave) my_off += S.wsum2[w]; total += S.wsum2[w]; }
+      if (total > kDmPool) {  // (the same in every thread)
+        if (tid == 0) atomicAdd(&g_dm_reason[3], 1u);
+        return;
+      }
+      uint32_t cq[2], sum = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t qi = tid * 2 + k;
+        cq[k] = qi < nR ? qcnt[qi] : 0u;
+        sum += cq[k];
+      }
+      const uint32_t inq = wave_incl_scan_u32(sum, (int)lane);
+      if (lane == 63) S.wsum3[wave] = inq;
+      __syncthreads();
+      uint32_t at = inq - sum;
+      for (uint32_t w = 0; w < wave; w++) at += S.wsum3[w];
+#pragma unroll
+      for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t qi = tid * 2 + k;
+        if (qi < nR) S.qoff[qi] = (uint16_t)at;
+        at += cq[k];
+      }
+    }
+    // the pairs: lcp of the source run's first pixel and the query (for the query's list and for its own match), and the
+    // source aligned with the end of the query's own run (as k_lz77_sparse does it for tiles with runs)
+    {
+      uint32_t n_done = 0;
+      uint32_t qi = q_first, next = 0, ip = 0, base = 0;
+      bool fresh = true;
+      uint64_t todo = hit;
+      while (todo) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t w = w0 + k;
+        if (fresh || w >= next) {
+          while (S.qps[qi + 1] <= w) qi++;
+          next = S.qps[qi + 1];
+          ip = query_index(qi);
+          base = (uint32_t)S.qbeg[qi] - S.qps[qi];
+          fresh = false;
+        }
+        const uint32_t s = S.items[base + w] & ((1u << kSpPosBits) - 1);
+        const uint32_t cap = W - ip < kMaxLen ? W - ip : kMaxLen;
+        const uint32_t e = lcp_runs(s, ip, cap);
+        if ((keep >> k) & 1u) {
+          uint32_t zb = s - S.rs[S.zr[s - 1]];
+          zb = zb < 127 ? zb : 127u;
+          S.pool[my_off + n_done++] = s | (zb << 12) | ((e < 127 ? e : 127u) << 19);
+        }
+        if (qi < nS) {  // the query's own match
+          const uint32_t p = lo + ip, rem = M - p < kMaxLen ? M - p : kMaxLen, d = ip - s;
+          uint32_t l = e < d ? e : d;
+          l = l < rem ? l : rem;
+          uint32_t key = (l << 11) | d;
+          const uint32_t F = S.runlen[ip], r = S.runlen[s];
+          if (F < kMaxLen && r > F && s + r <= ip) {
+            const uint32_t q2 = s + r - F, d2 = ip - q2, maxl = d2 < rem ? d2 : rem;
+            const uint32_t k2 = (lcp_runs(q2, ip, maxl) << 11) | d2;
+            key = k2 > key ? k2 : key;
+          }
+          atomicMax(&S.keys[qi], key);
+        }
+      }
+    }
+    __syncthreads();
+    // the queries' own matches (a run of the query's value that the window start cuts is one more source run)
+    for (uint32_t qi = tid; qi < nS; qi += kDmThreads) {
+      const uint32_t ip = S.others[qlo + qi], p = lo + ip, x = px[ip];
+      uint32_t key = S.keys[qi];
+      const uint32_t wlo = ip > kWindow ? ip - kWindow : 0u;
+      if (wlo > 0 && px[wlo] == x && px[wlo - 1] == x) {
+        const uint32_t rem = M - p < kMaxLen ? M - p : kMaxLen, F = S.runlen[ip], r = S.runlen[wlo];
+        const uint32_t d = ip - wlo, maxl = d < rem ? d : rem;
+        const uint32_t k1 = (lcp_runs(wlo, ip, maxl) << 11) | d;
+        key = k1 > key ? k1 : key;
+        if (F < kMaxLen && r > F && wlo + r <= ip) {
+          const uint32_t q2 = wlo + r - F, d2 = ip - q2, maxl2 = d2 < rem ? d2 : rem;
+          const uint32_t k2 = (lcp_runs(q2, ip, maxl2) << 11) | d2;
+          key = k2 > key ? k2 : key;
+        }
+      }
+      if (p == M - 1) key = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
+      const uint32_t o = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_code_of(xsize, xinv, key & 2047u) << 19)) : 0u;
+      match[pos0 + p] = o;
+      adv[pos0 + p] = (uint8_t)((o & 0xff) ? (o & 0xff) : 1u);
+    }
+
+    // ---- the stretch's positions inside runs of v0, one per thread
+    const uint32_t ip = sa + tid;
+    if (ip < sb_ && px[ip] == v0) {
+      const uint32_t p = lo + ip;
+      const uint32_t r = S.zr[ip], rs_own = S.rs[r], E = S.re[r];
+      const uint32_t rem = M - p < kMaxLen ? M - p : kMaxLen;
+      const uint32_t F = E - ip < rem ? E - ip : rem;
+      const uint32_t wlo = ip > kWindow ? ip - kWindow : 0u;
+      uint32_t key = 0;
+      {  // sources in the position's own run: the farthest one
+        const uint32_t s_own = rs_own > wlo ? rs_own : wlo, d_own = ip - s_own;
+        if (d_own) key = ((F < d_own ? F : d_own) << 11) | d_own;
+      }
+      // earlier runs: the first whose part inside the window is F long, else the longest (the first of those)
+      uint32_t q = S.zr[wlo];
+      if (q < r) {
+        uint32_t best = 0, best_s = 0;
+        bool found = false;
+        {
+          const uint32_t s = S.rs[q] > wlo ? S.rs[q] : wlo, l = (uint32_t)S.re[q] - s;
+          best = l < 255 ? l : 255;
+          best_s = s;
+          found = best >= F;
+          q++;
+        }
+        while (!found && q < r && (q & 7u)) {
+          const uint32_t l = S.len8[q];
+          if (l > best) { best = l; best_s = S.rs[q]; found = l >= F; }
+          q++;
+        }
+        while (!found && q + 8 <= r) {
+          const uint32_t g = S.grp[q >> 3], l = g >> 3;
+          if (l >= F) {  // the first run of the group that is F long (not the group's longest)
+            uint32_t k = 0;
+            while (S.len8[q + k] < F) k++;
+            best = S.len8[q + k];
+            best_s = S.rs[q + k];
+            found = true;
+          } else if (l > best) {
+            best = l;
+            best_s = S.rs[q + (g & 7u)];
+          }
+          q += 8;
+        }
+        while (!found && q < r) {
+          const uint32_t l = S.len8[q];
+          if (l > best) { best = l; best_s = S.rs[q]; found = l >= F; }
+          q++;
+        }
+        const uint32_t kk = ((best < F ? best : F) << 11) | (ip - best_s);
+        key = kk > key ? kk : key;
+      }
+      if (F < rem) {  // aligned sources: the list of the run's anchor (F < rem: the run ends inside the window, so it has one)
+        const uint32_t qa = E < sb_ ? (uint32_t)S.qof[r] - qlo : nS, off = S.qoff[qa], cnt = qcnt[qa];
+        for (uint32_t i = 0; i < cnt; i++) {
+          const uint32_t ent = S.pool[off + i];
+          if (((ent >> 12) & 127u) < F) continue;
+          const uint32_t d = ip + F - (ent & ((1u << kSpPosBits) - 1));
+          uint32_t l = F + (ent >> 19);
+          l = l < d ? l : d;
+          l = l < rem ? l : rem;
+          const uint32_t kk = (l << 11) | d;
+          key = kk > key ? kk : key;
+        }
+      }
+      if (p == M - 1) key = 0;
+      const uint32_t o = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_code_of(xsize, xinv, key & 2047u) << 19)) : 0u;
+      match[pos0 + p] = o;
+      adv[pos0 + p] = (uint8_t)((o & 0xff) ? (o & 0xff) : 1u);
+    }
+    __syncthreads();  // the stretch's keys, numbering and lists are the next stretch's
+  }
+  if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = kTileDoneDominant;
+}
+
+// The tiles that k_lz77_sparse left to the exhaustive kernel: a fixed grid, each workgroup looking at every gridDim.x-th
+// flag, 64 at a time (as k_lz77_pairs does).  A tile that is searched here gets the flag kTileDoneDominant; one that
+// is not (no frequent value, lists too long) keeps its flag and is the exhaustive kernel's.
+__global__ __launch_bounds__(kDmThreads, 4) void k_lz77_dominant(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                                 const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
+                                                                 const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
+                                                                 uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
+  __shared__ __attribute__((aligned(16))) DmShared S;
+  for (uint32_t base = blockIdx.x; base < ntiles; base += 64 * gridDim.x) {
+    const uint32_t mine = base + (threadIdx.x & 63u) * gridDim.x;
+    uint64_t marked = __ballot(mine < ntiles && dense_tile[mine] == kTileExhaustive);
+    while (marked) {
+      const uint32_t k = (uint32_t)__builtin_ctzll(marked);
+      marked &= marked - 1;
+      lz77_dominant_tile(S, imgs, st, sb_first, n, base + k * gridDim.x, pix, match, adv, dense_tile);
+      __syncthreads();  // the tile's shared memory is the next tile's
+    }
+  }
+}
+
+}  // namespace vp8l
