@@ -24,3 +24,12 @@ for rep in range(2):
     assert st[0] == 0
 L.vp8l_debug_dominant_reasons(buf)
 print("kinds", enc.last_tile_kinds(), "reasons over 2 calls [no frequent value, run starts, visits, pairs]", list(buf), "stage ms", {k: round(1e3 * v, 2) for k, v in enc.last_stage_seconds().items()})
+if hasattr(L, "vp8l_debug_dominant_phase_cycles"):
+    ph = (C.c_ulonglong * 12)()
+    L.vp8l_debug_dominant_phase_cycles(ph)
+    enc.encode_device([d_in.data_ptr()], [w], [h], d_out.data_ptr(), cap)
+    L.vp8l_debug_dominant_phase_cycles(ph)
+    names = ["load", "frequent value + segment pass", "buckets + run groups", "queries numbered", "walk", "offsets (wait for walks)", "pairs",
+             "wait for pairs", "own matches", "v0 positions", "wait for v0 positions", "-"]
+    tot = float(sum(ph)) or 1.0
+    print("phases:", ", ".join("%s %.1f%%" % (n, 100.0 * c / tot) for n, c in zip(names, ph) if c))

@@ -2197,7 +2197,7 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   h = h && hip_ok(hipMemsetAsync(B.st, 0, nl * sizeof(EncState), s), "clear state");
   h = h && hip_ok(hipMemsetAsync(B.gsets, 0xff, (size_t)nl * kSetSlots * sizeof(unsigned long long), s), "clear sets");
   h = h && hip_ok(hipMemsetAsync(B.histo, 0, (size_t)nl * kNumCodes * kCodeStride * 4, s), "clear histograms");
-  h = h && hip_ok(hipMemsetAsync(B.dense, 0, (size_t)sb_total * (kSuper / kLzTile), s), "clear tile flags");
+  h = h && hip_ok(hipMemsetAsync(B.dense, 0, (size_t)sb_total * (kSuper / kLzTile) + kDenseTail, s), "clear tile flags");  // and the work counter behind them
   if (!h) return VP8L_ERR_HIP;
   auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], s); };
   const uint32_t gsb = sb_total, gunits = sb_total * kUnitsPerSuper;
@@ -2226,7 +2226,8 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   }
   if (match_mode == 0 && g_tune[3])
     hipLaunchKernelGGL(k_lz77_dominant, dim3(std::min<uint32_t>(gsb * (kSuper / kSpTile), kDmGrid)), dim3(kDmThreads), 0, s, B.imgs, B.st, B.sbf, nl,
-                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense);
+                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense,
+                       reinterpret_cast<uint32_t *>(B.dense + (((size_t)sb_total * (kSuper / kLzTile) + 15) & ~(size_t)15)));
   mark(9);  // also when the candidate-list kernel is switched off
   hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,
                      match_mode == 0 ? B.dense : (const uint8_t *)nullptr);
@@ -2370,7 +2371,7 @@ static int vp8l_encoder_encode_device_impl(vp8l_encoder *e, size_t n, const uint
             e->d_histo.reserve((size_t)nl * kNumCodes * kCodeStride * 4) && e->d_tables.reserve((size_t)nl * sizeof(CodeTables)) &&
             e->d_sx.reserve(sb_total * kBlockLen) && e->d_entry.reserve(sb_total) &&
             e->d_unit_bits.reserve(nunits * 4) && e->d_unit_off.reserve(nunits * 8) &&
-            e->d_dense.reserve(sb_total * (kSuper / kLzTile)) && e->d_group_bits.reserve(npos / 16 * 2) && e->d_adv.reserve(npos) &&
+            e->d_dense.reserve(sb_total * (kSuper / kLzTile) + kDenseTail) && e->d_group_bits.reserve(npos / 16 * 2) && e->d_adv.reserve(npos) &&
             ((e->pred_bits == 0 && e->cross_bits == 0) ||
              (e->d_pix2.reserve(npos * 4) && e->d_modes.reserve((size_t)nl * kSmallMax * 4) && e->d_elems.reserve((size_t)nl * kSmallMax * 4)));
   if (!ok) return VP8L_ERR_NO_MEMORY;
@@ -2633,7 +2634,7 @@ constexpr uint64_t kNaEntry = kNaSx + na_align(kNaSuper * kBlockLen);
 constexpr uint64_t kNaUbits = kNaEntry + na_align(kNaSuper);
 constexpr uint64_t kNaUoff = kNaUbits + na_align(kNaSuper * kUnitsPerSuper * 4);
 constexpr uint64_t kNaDense = kNaUoff + na_align(kNaSuper * kUnitsPerSuper * 8);
-constexpr uint64_t kNaGbits = kNaDense + na_align(kNaSuper * (kSuper / kLzTile));
+constexpr uint64_t kNaGbits = kNaDense + na_align(kNaSuper * (kSuper / kLzTile) + kDenseTail);
 constexpr uint64_t kNaFlags = kNaGbits + na_align(kNaPos / 16 * 2);
 constexpr uint64_t kNaAdv = kNaFlags + na_align(kNaPos / 8);
 constexpr uint64_t kNaPix = kNaAdv + na_align(kNaPos);
@@ -2780,6 +2781,13 @@ extern "C" int vp8l_debug_dominant_reasons(unsigned int *out4) {
 
 #ifdef VP8L_PHASE_TIMING
 // Measurement builds only: cycles per phase of k_lz77_sparse summed over the workgroups since the last call (then cleared).
+extern "C" int vp8l_debug_dominant_phase_cycles(unsigned long long *out12) {
+  if (!hip_ok(hipDeviceSynchronize(), "sync")) return VP8L_ERR_HIP;
+  if (!hip_ok(hipMemcpyFromSymbol(out12, HIP_SYMBOL(vp8l::g_dm_phase), 12 * sizeof(unsigned long long)), "read phase counters")) return VP8L_ERR_HIP;
+  unsigned long long zero[12] = {};
+  if (!hip_ok(hipMemcpyToSymbol(HIP_SYMBOL(vp8l::g_dm_phase), zero, sizeof(zero)), "clear phase counters")) return VP8L_ERR_HIP;
+  return VP8L_OK;
+}
 extern "C" int vp8l_debug_phase_cycles(unsigned long long *out8) {
   if (!hip_ok(hipDeviceSynchronize(), "sync")) return VP8L_ERR_HIP;
   if (!hip_ok(hipMemcpyFromSymbol(out8, HIP_SYMBOL(vp8l::g_sp_phase), 8 * sizeof(unsigned long long)), "read phase counters")) return VP8L_ERR_HIP;

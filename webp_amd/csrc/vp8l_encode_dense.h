@@ -35,7 +35,8 @@ constexpr uint32_t kDmSeg = 7;                             // window pixels per 
 constexpr uint32_t kDmMaxStarts = 1024;                    // run starts of other values a window may hold
 constexpr uint32_t kDmMaxRuns = kDmMaxStarts + 2;          // runs of v0 in a window: something else stands between two of them
 constexpr uint32_t kDmSub = 512;                           // positions of a tile that are searched together (a stretch)
-constexpr uint32_t kDmPool = 3072;                         // scored (query, source) pairs of a tile
+constexpr uint32_t kDmMinSub = 32;                         // ... down to this many where the queries find too much
+constexpr uint32_t kDmPool = 3072;                         // (query, source) pairs of a stretch
 constexpr uint32_t kDmMaxVisits = kDmThreads * 64;         // bucket entries all queries of a tile may have to look at
 constexpr uint32_t kDmGrid = 2048;                         // workgroups (two fit a CU)
 constexpr uint8_t kTileDoneDominant = 4;                   // tile flag: searched by k_lz77_dominant
@@ -46,9 +47,26 @@ static_assert(kDmMaxW <= (1u << kSpPosBits), "window indices fit an entry");
 // [0] no frequent value, [1] too many run starts of other values, [2] too many bucket entries to look at, [3] too many pairs
 __device__ unsigned int g_dm_reason[4];
 
+// Per-phase cycle counts (a measurement build only, -DVP8L_PHASE_TIMING: thread 0 of every workgroup adds the cycles
+// between phase marks; read with vp8l_debug_dominant_phase_cycles)
+#ifdef VP8L_PHASE_TIMING
+__device__ unsigned long long g_dm_phase[12];
+#define DM_PHASE_BEGIN() unsigned long long dm_t = __builtin_readcyclecounter()
+#define DM_PHASE_MARK(k)                                                       \
+  do {                                                                          \
+    const unsigned long long dm_n = __builtin_readcyclecounter();               \
+    if (threadIdx.x == 0) atomicAdd(&g_dm_phase[k], dm_n - dm_t);               \
+    dm_t = dm_n;                                                                \
+  } while (0)
+#else
+#define DM_PHASE_BEGIN() do {} while (0)
+#define DM_PHASE_MARK(k) do {} while (0)
+#endif
+
 struct DmShared {
   uint32_t px[kDmMaxW + 4];
-  uint32_t pool[kDmPool];           // the anchors' lists of a stretch, in the order of the queries: source index | v0 pixels in front of it << 12 | lcp << 19
+  uint32_t pool[kDmPool];           // the pairs (query, source) of a stretch, in the order of the queries: first query | source << 10, then
+                                    // source | v0 pixels in front of it << 12 | lcp << 19 (a query's pairs are its list)
   uint32_t keys[kDmSub + 2];        // per query of the stretch: its best match so far, length << 11 | distance
   uint32_t cursor2[kSpBuckets / 2]; // bucket ends, 16 bits each
   uint32_t items[kDmMaxStarts];     // run starts of the other values: tag | index
@@ -62,30 +80,45 @@ struct DmShared {
   uint16_t qbeg[kDmSub + 2];        // per query of the stretch: where its bucket begins in items
   uint16_t qps[kDmSub + 4];         // per query of the stretch: bucket entries of the queries before it (and the total behind the last)
   uint16_t qoff[kDmSub + 4];        // per query of the stretch: where its list begins in pool
+  uint16_t subq[kDmTile / kDmSub + 1];  // per stretch of the tile: tile positions of other values in front of it
   uint8_t len8[kDmMaxRuns];         // run lengths capped at 255
   uint32_t wsum[kDmWaves], wsum2[kDmWaves], wsum3[kDmWaves], wmin[kDmWaves];
 };
 
-__device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
-                                                   const uint32_t *__restrict__ sb_first, uint32_t n, const uint32_t tile,
-                                                   const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
-                                                   uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
+// Where a tile lies: its image's coded size and width, its positions [a, b), the window [lo, hi) around them
+struct DmGeo {
+  uint32_t M, xsize, xinv, a, b, lo, W;
+  uint64_t pos0;
+};
+
+__device__ __forceinline__ DmGeo dm_geometry(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                             const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t tile) {
   constexpr uint32_t kPerSuper = kSuper / kDmTile;
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  DmGeo g;
   const uint32_t sb = tile / kPerSuper, img = find_image(sb_first, n, sb);
-  const uint32_t M = st[img].M, xsize = st[img].xsize, xinv = st[img].xinv;
-  const uint32_t a = (tile - sb_first[img] * kPerSuper) * kDmTile;
-  if (a >= M) return;
-  const uint32_t b = a + kDmTile < M ? a + kDmTile : M;
-  const uint32_t lo = a > kWindow ? a - kWindow : 0;
-  const uint32_t hi = b + kMaxLen - 1 < M ? b + kMaxLen - 1 : M;
-  const uint32_t W = hi - lo;
-  const uint64_t pos0 = imgs[img].pos0;
-  const uint32_t *data = pix + pos0;
+  g.M = st[img].M; g.xsize = st[img].xsize; g.xinv = st[img].xinv;
+  g.a = (tile - sb_first[img] * kPerSuper) * kDmTile;
+  g.b = g.a + kDmTile < g.M ? g.a + kDmTile : g.M;
+  g.lo = g.a > kWindow ? g.a - kWindow : 0;
+  const uint32_t hi = g.b + kMaxLen - 1 < g.M ? g.b + kMaxLen - 1 : g.M;
+  g.W = g.a < g.M ? hi - g.lo : 0;  // 0: the tile holds no pixels
+  g.pos0 = imgs[img].pos0;
+  return g;
+}
+
+constexpr uint32_t kDmLoads = (kDmMaxW + 4 * kDmThreads - 1) / (4 * kDmThreads);  // 16-byte loads per thread for a window
+
+// The tile's window must be in S.px (dm_commit_window) before the call.
+__device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, uint32_t *__restrict__ match,
+                                                   uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t M = G.M, xsize = G.xsize, xinv = G.xinv, a = G.a, b = G.b, lo = G.lo, W = G.W;
+  const uint64_t pos0 = G.pos0;
   uint32_t *px = S.px;
+  DM_PHASE_BEGIN();
   for (uint32_t i = tid; i < kSpBuckets / 2; i += kDmThreads) S.cursor2[i] = 0;
-  for (uint32_t i = tid * 4; i < W; i += kDmThreads * 4) *reinterpret_cast<uint4 *>(&px[i]) = *reinterpret_cast<const uint4 *>(data + lo + i);
   __syncthreads();
+  DM_PHASE_MARK(0);  // (the window was loaded ahead)
 
   // ---- the frequent value
   const uint32_t s0 = tid * kDmSeg;
@@ -174,6 +207,8 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *
         S.zr[i] = (uint16_t)k;
         if ((starts0 >> j) & 1u) S.rs[k] = (uint16_t)i;
         if ((ends0 >> j) & 1u) S.re[k] = (uint16_t)(i + 1);
+        if (i >= a - lo && i < b - lo && ((i - (a - lo)) & (kDmSub - 1)) == 0)  // queries in front of every stretch of the tile
+          S.subq[(i - (a - lo)) / kDmSub] = (uint16_t)(base_m + (uint32_t)__popc(mine_other & ((1u << j) - 1u)));
         if ((mine_other >> j) & 1u) {
           const uint32_t qi = base_m + (uint32_t)__popc(mine_other & ((1u << j) - 1u));
           S.others[qi] = (uint16_t)i;
@@ -189,6 +224,7 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *
       }
   }
   __syncthreads();
+  DM_PHASE_MARK(1);  // frequent value, segment pass
   uint32_t R = 0, n_other_starts = 0, n_mine = 0;
   for (uint32_t w = 0; w < kDmWaves; w++) { R += S.wsum[w]; n_other_starts += S.wsum2[w]; n_mine += S.wsum3[w]; }
   // exclusive scan of the bucket counts (8 per thread), then the scatter; afterwards cursor[h] = end of bucket h
@@ -235,6 +271,7 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *
     S.grp[g] = (uint16_t)((best << 3) | at);
   }
   __syncthreads();
+  DM_PHASE_MARK(2);  // buckets, run groups
   const uint16_t *cursor = reinterpret_cast<const uint16_t *>(S.cursor2);
   const uint16_t *qcnt = reinterpret_cast<const uint16_t *>(S.qcnt2);
   const uint32_t ia = a - lo, ib = b - lo;
@@ -252,7 +289,11 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *
   // ---- the tile in stretches of kDmSub positions: first the queries of the stretch (its positions of other values, in
   // order, and behind them the anchor of the run that holds the stretch's last pixel, if that anchor lies behind the
   // stretch: its list is needed, its own match is not), then the stretch's positions inside runs of v0.
-  auto first_query_at = [&](uint32_t index) {  // number of queries (tile positions of other values) in front of window index `index`
+  // A stretch whose queries have more bucket entries to look at, or find more pairs, than there is room for is tried
+  // again at half its length (down to kDmMinSub positions; then the tile is the exhaustive kernel's).
+  auto queries_before = [&](uint32_t index) -> uint32_t {  // tile positions of other values in front of window index `index`
+    if (index >= ib) return n_mine;
+    if (((index - ia) & (kDmSub - 1)) == 0) return S.subq[(index - ia) / kDmSub];
     uint32_t l = 0, h = n_mine;
     while (l < h) {
       const uint32_t mid = (l + h) >> 1;
@@ -260,9 +301,10 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *
     }
     return l;
   };
-  for (uint32_t sa = ia; sa < ib; sa += kDmSub) {
-    const uint32_t sb_ = sa + kDmSub < ib ? sa + kDmSub : ib;
-    const uint32_t qlo = first_query_at(sa), nS = first_query_at(sb_) - qlo;
+  uint32_t sub = kDmSub;
+  for (uint32_t sa = ia; sa < ib;) {
+    const uint32_t sb_ = sa + sub < ib ? sa + sub : ib;
+    const uint32_t qlo = queries_before(sa), nS = queries_before(sb_) - qlo;
     uint32_t nR = nS, extra_ip = 0;
     if (px[sb_ - 1] == v0) {
       const uint32_t c0 = S.re[S.zr[sb_ - 1]];
@@ -290,7 +332,8 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *
       __syncthreads();
       uint32_t at = incl - sum, total = 0;
       for (uint32_t w = 0; w < kDmWaves; w++) { if (w < wave) at += S.wsum[w]; total += S.wsum[w]; }
-      if (total > kDmMaxVisits) {  // (every thread sees the same total) too much to look at: the exhaustive kernel's tile
+      if (total > kDmMaxVisits) {  // (every thread sees the same total) too much to look at
+        if (sub > kDmMinSub) { sub >>= 1; __syncthreads(); continue; }
         if (tid == 0) atomicAdd(&g_dm_reason[2], 1u);
         return;
       }
@@ -303,12 +346,12 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *
     }
     static_assert(kDmThreads * 2 >= kDmSub + 2 && kDmMaxVisits < 65536, "query scan");
     __syncthreads();
+    DM_PHASE_MARK(3);  // the stretch's queries numbered
     const uint32_t T = S.qps[nR];
     const uint32_t K = (T + kDmThreads - 1) / kDmThreads;  // visits per thread, at most 64
     const uint32_t w0 = tid * K < T ? tid * K : T, w1 = w0 + K < T ? w0 + K : T;
-    // the walk: which of this thread's visits find a source of the query's value among the 1024 before it (`hit`), and
-    // which of those belong in the query's list: the query is an anchor and the source follows a pixel of v0 (`keep`)
-    uint64_t hit = 0, keep = 0;
+    // the walk: which of this thread's visits find a source of the query's value among the 1024 before it
+    uint64_t hit = 0;
     uint32_t q_first = 0;
     if (w0 < w1) {
       uint32_t lo_q = 0, hi_q = nR;  // largest qi with qps[qi] <= w0
@@ -320,7 +363,7 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *
     }
     {
       uint32_t qi = q_first, next = 0, ip = 0, tag = 0, base = 0, local = 0;
-      bool fresh = true, anchor = false;
+      bool fresh = true;
       for (uint32_t w = w0; w < w1; w++) {
         if (fresh || w >= next) {
           if (!fresh && local) { atomicAdd(&S.qcnt2[qi >> 1], local << (16 * (qi & 1u))); local = 0; }
@@ -329,28 +372,30 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *
           ip = query_index(qi);
           tag = (px[ip] * kSpMul) << kSpTagShift;
           base = (uint32_t)S.qbeg[qi] - S.qps[qi];
-          anchor = ip > 0 && px[ip - 1] == v0;
           fresh = false;
         }
         const uint32_t it = S.items[base + w], s = it & ((1u << kSpPosBits) - 1);
         if ((it ^ tag) >> kSpPosBits || s >= ip || s + kWindow < ip) continue;
-        const bool listed = anchor && s > 0 && px[s - 1] == v0;
-        if (qi < nS || listed) hit |= 1ull << (w - w0);
-        if (listed) { keep |= 1ull << (w - w0); local++; }
+        hit |= 1ull << (w - w0);
+        local++;
       }
       if (local) atomicAdd(&S.qcnt2[qi >> 1], local << (16 * (qi & 1u)));
     }
-    // where every thread's list entries go (the order of the visits is the order of the queries), and where every query's begin
-    uint32_t my_off = 0;
+    DM_PHASE_MARK(4);  // the walk
+    // The pairs found go into `pool` in the order of the visits, which is the order of the queries: every query's pairs
+    // are a stretch of it (its list).  First as (query, source); then every thread takes every kDmThreads-th pair, whoever
+    // found it, and replaces it by what the list holds (so a thread that walked through a long bucket of its own
+    // query's value does not score all of it alone).
+    uint32_t n_pairs = 0;
     {
-      const uint32_t c = (uint32_t)__popcll(keep);
+      const uint32_t c = (uint32_t)__popcll(hit);
       const uint32_t incl = wave_incl_scan_u32(c, (int)lane);
       if (lane == 63) S.wsum2[wave] = incl;
       __syncthreads();  // the counts per query are complete, too
-      uint32_t total = 0;
-      my_off = incl - c;
-      for (uint32_t w = 0; w < kDmWaves; w++) { if (w < wave) my_off += S.wsum2[w]; total += S.wsum2[w]; }
-      if (total > kDmPool) {  // (the same in every thread)
+      uint32_t my_off = incl - c;
+      for (uint32_t w = 0; w < kDmWaves; w++) { if (w < wave) my_off += S.wsum2[w]; n_pairs += S.wsum2[w]; }
+      if (n_pairs > kDmPool) {  // (the same in every thread)
+        if (sub > kDmMinSub) { sub >>= 1; __syncthreads(); continue; }
         if (tid == 0) atomicAdd(&g_dm_reason[3], 1u);
         return;
       }
@@ -363,21 +408,7 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *
       }
       const uint32_t inq = wave_incl_scan_u32(sum, (int)lane);
       if (lane == 63) S.wsum3[wave] = inq;
-      __syncthreads();
-      uint32_t at = inq - sum;
-      for (uint32_t w = 0; w < wave; w++) at += S.wsum3[w];
-#pragma unroll
-      for (uint32_t k = 0; k < 2; k++) {
-        const uint32_t qi = tid * 2 + k;
-        if (qi < nR) S.qoff[qi] = (uint16_t)at;
-        at += cq[k];
-      }
-    }
-    // the pairs: lcp of the source run's first pixel and the query (for the query's list and for its own match), and the
-    // source aligned with the end of the query's own run (as k_lz77_sparse does it for tiles with runs)
-    {
-      uint32_t n_done = 0;
-      uint32_t qi = q_first, next = 0, ip = 0, base = 0;
+      uint32_t qi = q_first, next = 0, base = 0;
       bool fresh = true;
       uint64_t todo = hit;
       while (todo) {
@@ -387,34 +418,53 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *
         if (fresh || w >= next) {
           while (S.qps[qi + 1] <= w) qi++;
           next = S.qps[qi + 1];
-          ip = query_index(qi);
           base = (uint32_t)S.qbeg[qi] - S.qps[qi];
           fresh = false;
         }
-        const uint32_t s = S.items[base + w] & ((1u << kSpPosBits) - 1);
-        const uint32_t cap = W - ip < kMaxLen ? W - ip : kMaxLen;
-        const uint32_t e = lcp_runs(s, ip, cap);
-        if ((keep >> k) & 1u) {
-          uint32_t zb = s - S.rs[S.zr[s - 1]];
-          zb = zb < 127 ? zb : 127u;
-          S.pool[my_off + n_done++] = s | (zb << 12) | ((e < 127 ? e : 127u) << 19);
-        }
-        if (qi < nS) {  // the query's own match
-          const uint32_t p = lo + ip, rem = M - p < kMaxLen ? M - p : kMaxLen, d = ip - s;
-          uint32_t l = e < d ? e : d;
-          l = l < rem ? l : rem;
-          uint32_t key = (l << 11) | d;
-          const uint32_t F = S.runlen[ip], r = S.runlen[s];
-          if (F < kMaxLen && r > F && s + r <= ip) {
-            const uint32_t q2 = s + r - F, d2 = ip - q2, maxl = d2 < rem ? d2 : rem;
-            const uint32_t k2 = (lcp_runs(q2, ip, maxl) << 11) | d2;
-            key = k2 > key ? k2 : key;
-          }
-          atomicMax(&S.keys[qi], key);
-        }
+        S.pool[my_off++] = qi | ((S.items[base + w] & ((1u << kSpPosBits) - 1)) << 10);
+      }
+      __syncthreads();
+      uint32_t at = inq - sum;
+      for (uint32_t w = 0; w < wave; w++) at += S.wsum3[w];
+#pragma unroll
+      for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t qk = tid * 2 + k;
+        if (qk < nR) S.qoff[qk] = (uint16_t)at;
+        at += cq[k];
       }
     }
+    static_assert(kDmSub + 2 <= (1u << 10), "a query's number fits ten bits of a pair");
+    DM_PHASE_MARK(5);  // the pairs listed (after waiting for the slowest walk)
+    // the pairs: lcp of the source run's first pixel and the query (for the query's list and for its own match), and the
+    // source aligned with the end of the query's own run (as k_lz77_sparse does it for tiles with runs)
+    for (uint32_t j = tid; j < n_pairs; j += kDmThreads) {
+      const uint32_t pr = S.pool[j], qi = pr & 1023u, s = pr >> 10;
+      const uint32_t ip = query_index(qi);
+      const uint32_t cap = W - ip < kMaxLen ? W - ip : kMaxLen;
+      const uint32_t e = lcp_runs(s, ip, cap);
+      uint32_t zb = 0;  // pixels of v0 in front of the source: 0 keeps it out of every list
+      if (s > 0 && px[s - 1] == v0) {
+        zb = s - S.rs[S.zr[s - 1]];
+        zb = zb < 127 ? zb : 127u;
+      }
+      S.pool[j] = s | (zb << 12) | ((e < 127 ? e : 127u) << 19);
+      if (qi < nS) {  // the query's own match
+        const uint32_t p = lo + ip, rem = M - p < kMaxLen ? M - p : kMaxLen, d = ip - s;
+        uint32_t l = e < d ? e : d;
+        l = l < rem ? l : rem;
+        uint32_t key = (l << 11) | d;
+        const uint32_t F = S.runlen[ip], r = S.runlen[s];
+        if (F < kMaxLen && r > F && s + r <= ip) {
+          const uint32_t q2 = s + r - F, d2 = ip - q2, maxl = d2 < rem ? d2 : rem;
+          const uint32_t k2 = (lcp_runs(q2, ip, maxl) << 11) | d2;
+          key = k2 > key ? k2 : key;
+        }
+        atomicMax(&S.keys[qi], key);
+      }
+    }
+    DM_PHASE_MARK(6);  // the pairs
     __syncthreads();
+    DM_PHASE_MARK(7);  // waiting for the slowest thread's pairs
     // the queries' own matches (a run of the query's value that the window start cuts is one more source run)
     for (uint32_t qi = tid; qi < nS; qi += kDmThreads) {
       const uint32_t ip = S.others[qlo + qi], p = lo + ip, x = px[ip];
@@ -437,6 +487,7 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *
       adv[pos0 + p] = (uint8_t)((o & 0xff) ? (o & 0xff) : 1u);
     }
 
+    DM_PHASE_MARK(8);  // own matches stored
     // ---- the stretch's positions inside runs of v0, one per thread
     const uint32_t ip = sa + tid;
     if (ip < sb_ && px[ip] == v0) {
@@ -507,28 +558,71 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const EncImage *
       match[pos0 + p] = o;
       adv[pos0 + p] = (uint8_t)((o & 0xff) ? (o & 0xff) : 1u);
     }
+    DM_PHASE_MARK(9);  // positions of v0
     __syncthreads();  // the stretch's keys, numbering and lists are the next stretch's
+    DM_PHASE_MARK(10);  // waiting for the slowest of them
+    sa = sb_;
+    if (((sa - ia) & (kDmSub - 1)) == 0) sub = kDmSub;  // back to whole stretches at their borders
   }
   if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = kTileDoneDominant;
 }
 
-// The tiles that k_lz77_sparse left to the exhaustive kernel: a fixed grid, each workgroup looking at every gridDim.x-th
-// flag, 64 at a time (as k_lz77_pairs does).  A tile that is searched here gets the flag kTileDoneDominant; one that
-// is not (no frequent value, lists too long) keeps its flag and is the exhaustive kernel's.
+// The tiles that k_lz77_sparse left to the exhaustive kernel.  Workgroups stay and take tiles from a counter, 16
+// consecutive tile numbers at a time (a look at their flags tells which of them are waiting); the window of a
+// workgroup's next tile is on its way from memory, into registers, while the current one is searched.  A tile that is
+// searched here gets the flag kTileDoneDominant; one that is not (no frequent value, too many run starts or list
+// entries) keeps its flag and is the exhaustive kernel's.  `counter` starts at 0 (cleared with the flags).
+constexpr uint32_t kDmChunk = 16;
 __global__ __launch_bounds__(kDmThreads, 4) void k_lz77_dominant(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                                  const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
                                                                  const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
-                                                                 uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
+                                                                 uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile,
+                                                                 uint32_t *__restrict__ counter) {
   __shared__ __attribute__((aligned(16))) DmShared S;
-  for (uint32_t base = blockIdx.x; base < ntiles; base += 64 * gridDim.x) {
-    const uint32_t mine = base + (threadIdx.x & 63u) * gridDim.x;
-    uint64_t marked = __ballot(mine < ntiles && dense_tile[mine] == kTileExhaustive);
-    while (marked) {
-      const uint32_t k = (uint32_t)__builtin_ctzll(marked);
-      marked &= marked - 1;
-      lz77_dominant_tile(S, imgs, st, sb_first, n, base + k * gridDim.x, pix, match, adv, dense_tile);
-      __syncthreads();  // the tile's shared memory is the next tile's
+  __shared__ uint32_t s_chunk;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  uint32_t chunk = 0;
+  uint64_t waiting = 0;  // tiles of the chunk that are still to do (the same in every thread)
+  // the next waiting tile, or ~0u when the counter has run past the last tile; called by all threads
+  auto next_tile = [&]() -> uint32_t {
+    for (;;) {
+      if (waiting) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(waiting);
+        waiting &= waiting - 1;
+        return chunk + k;
+      }
+      if (tid == 0) s_chunk = atomicAdd(counter, kDmChunk);
+      __syncthreads();
+      chunk = s_chunk;
+      __syncthreads();  // everyone has read it before it is written again
+      if (chunk >= ntiles) return ~0u;
+      waiting = __ballot(lane < kDmChunk && chunk + lane < ntiles && dense_tile[chunk + lane] == kTileExhaustive);
     }
+  };
+  uint4 ahead[kDmLoads];
+  auto fetch_window = [&](const DmGeo &g) {
+    const uint32_t *data = pix + g.pos0 + g.lo;  // lo is a multiple of 4 and the pixel array has readable slack past M: 16-byte loads
+#pragma unroll
+    for (uint32_t k = 0; k < kDmLoads; k++) {
+      const uint32_t i = (k * kDmThreads + tid) * 4;
+      ahead[k] = i < g.W ? *reinterpret_cast<const uint4 *>(data + i) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  uint32_t tile = next_tile();
+  DmGeo geo;
+  if (tile != ~0u) { geo = dm_geometry(imgs, st, sb_first, n, tile); fetch_window(geo); }
+  while (tile != ~0u) {
+#pragma unroll
+    for (uint32_t k = 0; k < kDmLoads; k++) {
+      const uint32_t i = (k * kDmThreads + tid) * 4;
+      if (i < geo.W) *reinterpret_cast<uint4 *>(&S.px[i]) = ahead[k];
+    }
+    const DmGeo cur = geo;
+    const uint32_t following = next_tile();  // (its barriers also make the window visible to everyone)
+    if (following != ~0u) { geo = dm_geometry(imgs, st, sb_first, n, following); fetch_window(geo); }
+    if (cur.W) lz77_dominant_tile(S, cur, match, adv, dense_tile);
+    __syncthreads();  // the tile's shared memory is the next tile's
+    tile = following;
   }
 }
 

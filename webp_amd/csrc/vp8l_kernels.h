@@ -22,6 +22,7 @@ constexpr uint32_t kLzBlock = kLzTile * kLzWaves;
 constexpr uint32_t kLzHead = 1024;      // positions at the start of an image that have fewer than 1024 distances (= the window)
 constexpr uint32_t kLzHeadPiece = 128;  // ... searched in pieces of this many
 constexpr uint32_t kTailPad = 64;       // readable slack behind every image's region
+constexpr uint32_t kDenseTail = 64;     // bytes behind the per-tile flags of the match search: a work counter, cleared with them
 
 struct EncImage {          // host-written
   const uint32_t *argb;
