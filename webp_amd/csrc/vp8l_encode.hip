@@ -707,6 +707,7 @@ static_assert(kSpTile / kSpThreads == 4, "positions of a thread are handled as t
 // `grouped` below): with that path compiled in, the common path of this kernel got 12 % slower (60 instead of 40
 // registers, other schedules), and those tiles are few or many by the kind of image, so they are listed and redone.
 constexpr uint8_t kTileExhaustive = 1, kTilePairs = 2;
+constexpr uint8_t kTileDoneDominant = 4;  // searched by k_lz77_dominant (vp8l_encode_dense.h), before or after this kernel
 template <bool PAIRS_KERNEL>
 __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                  const uint32_t *__restrict__ sb_first, uint32_t n, const uint32_t tile,
@@ -739,6 +740,7 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
   const uint32_t W = hi - lo;
   const uint64_t pos0 = imgs[img].pos0;
   if (PAIRS_KERNEL && dense_tile[(pos0 + a) / kLzTile] != kTilePairs) return;
+  if (!PAIRS_KERNEL && dense_tile[(pos0 + a) / kLzTile] == kTileDoneDominant) return;  // (only when that kernel ran first)
   const uint32_t *data = pix + pos0;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   VP8L_PHASE_BEGIN();
@@ -2219,15 +2221,22 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   mark(2);
   if (match_mode == 0)
   {
+    uint32_t *dm_counter = reinterpret_cast<uint32_t *>(B.dense + (((size_t)sb_total * (kSuper / kLzTile) + 15) & ~(size_t)15));
+    const uint32_t dm_grid = std::min<uint32_t>(gsb * (kSuper / kSpTile), kDmGrid);
+    // After the predictor the planes are mostly one value in runs, which the candidate lists give up on after spending their budget:
+    // there the kernel made for such tiles looks at every tile first and leaves the candidate lists what suits them.
+    const bool dominant_first = pred != 0 && (g_tune[3] & 1u);
+    if (dominant_first)
+      hipLaunchKernelGGL(k_lz77_dominant, dim3(dm_grid), dim3(kDmThreads), 0, s, B.imgs, B.st, B.sbf, nl, gsb * (kSuper / kSpTile), B.pix, B.match,
+                         B.adv8, B.dense, dm_counter, 0u);
     hipLaunchKernelGGL(k_lz77_sparse, dim3((gsb * (kSuper / kSpTile) + 7) / 8 * 8), dim3(kSpThreads), 0, s, B.imgs, B.st, B.sbf, nl,
                        gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0], g_tune[1], tune_max_bucket);
     hipLaunchKernelGGL(k_lz77_pairs, dim3(std::min<uint32_t>(gsb * (kSuper / kSpTile), kSpPairsGrid)), dim3(kSpThreads), 0, s, B.imgs, B.st, B.sbf, nl,
                        gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0], g_tune[1], tune_max_bucket);
+    if (g_tune[3] & 1u)  // what the candidate lists gave up on (after a first look: what that left them and they could not do either)
+      hipLaunchKernelGGL(k_lz77_dominant, dim3(dm_grid), dim3(kDmThreads), 0, s, B.imgs, B.st, B.sbf, nl, gsb * (kSuper / kSpTile), B.pix, B.match,
+                         B.adv8, B.dense, dm_counter + 1, (uint32_t)kTileExhaustive);
   }
-  if (match_mode == 0 && g_tune[3])
-    hipLaunchKernelGGL(k_lz77_dominant, dim3(std::min<uint32_t>(gsb * (kSuper / kSpTile), kDmGrid)), dim3(kDmThreads), 0, s, B.imgs, B.st, B.sbf, nl,
-                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense,
-                       reinterpret_cast<uint32_t *>(B.dense + (((size_t)sb_total * (kSuper / kLzTile) + 15) & ~(size_t)15)));
   mark(9);  // also when the candidate-list kernel is switched off
   hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,
                      match_mode == 0 ? B.dense : (const uint8_t *)nullptr);

@@ -34,12 +34,12 @@ constexpr uint32_t kDmMaxW = kWindow + kDmTile + kMaxLen;  // the 1024 before th
 constexpr uint32_t kDmSeg = 7;                             // window pixels per thread in the segment pass
 constexpr uint32_t kDmMaxStarts = 1024;                    // run starts of other values a window may hold
 constexpr uint32_t kDmMaxRuns = kDmMaxStarts + 2;          // runs of v0 in a window: something else stands between two of them
-constexpr uint32_t kDmSub = 512;                           // positions of a tile that are searched together (a stretch)
+constexpr uint32_t kDmSub = 1024;                          // positions of a tile that are searched together (a stretch)
 constexpr uint32_t kDmMinSub = 32;                         // ... down to this many where the queries find too much
 constexpr uint32_t kDmPool = 3072;                         // (query, source) pairs of a stretch
 constexpr uint32_t kDmMaxVisits = kDmThreads * 64;         // bucket entries all queries of a tile may have to look at
 constexpr uint32_t kDmGrid = 2048;                         // workgroups (two fit a CU)
-constexpr uint8_t kTileDoneDominant = 4;                   // tile flag: searched by k_lz77_dominant
+constexpr uint32_t kDmFewRuns = 32;                        // when this kernel looks first: fewer runs of the frequent value than this are left to the candidate lists
 static_assert(kDmThreads * kDmSeg >= kDmMaxW, "segment pass covers the window");
 static_assert(kDmMaxW <= (1u << kSpPosBits), "window indices fit an entry");
 
@@ -65,7 +65,7 @@ __device__ unsigned long long g_dm_phase[12];
 
 struct DmShared {
   uint32_t px[kDmMaxW + 4];
-  uint32_t pool[kDmPool];           // the pairs (query, source) of a stretch, in the order of the queries: first query | source << 10, then
+  uint32_t pool[kDmPool];           // the pairs (query, source) of a stretch, in the order of the queries: first query | source << 11, then
                                     // source | v0 pixels in front of it << 12 | lcp << 19 (a query's pairs are its list)
   uint32_t keys[kDmSub + 2];        // per query of the stretch: its best match so far, length << 11 | distance
   uint32_t cursor2[kSpBuckets / 2]; // bucket ends, 16 bits each
@@ -109,8 +109,10 @@ __device__ __forceinline__ DmGeo dm_geometry(const EncImage *__restrict__ imgs, 
 constexpr uint32_t kDmLoads = (kDmMaxW + 4 * kDmThreads - 1) / (4 * kDmThreads);  // 16-byte loads per thread for a window
 
 // The tile's window must be in S.px (dm_commit_window) before the call.
+// first_look: the candidate lists have not seen the tile yet and take it if it is left (then only tiles with many runs of the
+// frequent value are searched here).
 __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, uint32_t *__restrict__ match,
-                                                   uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
+                                                   uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile, bool first_look) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t M = G.M, xsize = G.xsize, xinv = G.xinv, a = G.a, b = G.b, lo = G.lo, W = G.W;
   const uint64_t pos0 = G.pos0;
@@ -126,18 +128,16 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
 #pragma unroll
   for (uint32_t j = 0; j <= kDmSeg; j++) v[j] = s0 + j < W ? px[s0 + j] : 0u;
   const uint32_t prev = s0 > 0 && s0 - 1 < W ? px[s0 - 1] : 0u;
-  // the commonest among 64 samples of the window (every wave finds it for itself, with the same result)
+  // the commonest among 64 samples of the window, of which 16 stand for election (every wave finds it for itself, with the same result)
   uint32_t v0;
   {
     const uint32_t smp = px[(2 * lane + 1) * W / 128];
-    uint32_t votes = 0;
+    uint32_t best = 0;  // votes << 6 | 63 - lane of the probe with the most votes among 16 of the 64 samples (the first among equals)
 #pragma unroll
-    for (int k = 0; k < 64; k++) votes += (uint32_t)__builtin_amdgcn_readlane((int)smp, k) == smp ? 1u : 0u;
-    uint32_t best = (votes << 6) | (63u - lane);  // most votes, the first lane among equals
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t other = (uint32_t)__shfl_xor((int)best, o, 64);
-      best = other > best ? other : best;
+    for (int k = 0; k < 64; k += 4) {
+      const uint32_t votes = (uint32_t)__popcll(__ballot((uint32_t)__builtin_amdgcn_readlane((int)smp, k) == smp));
+      const uint32_t cand = (votes << 6) | (63u - (uint32_t)k);
+      best = cand > best ? cand : best;
     }
     if ((best >> 6) < 6) {  // no value holds a tenth of the samples: the tile stays with the exhaustive kernel
       if (tid == 0) atomicAdd(&g_dm_reason[0], 1u);
@@ -187,6 +187,11 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
       if (starts > kDmMaxStarts) {  // (the same in every thread)
         if (tid == 0) atomicAdd(&g_dm_reason[1], 1u);
         return;
+      }
+      if (first_look) {
+        uint32_t runs = 0;
+        for (uint32_t w = 0; w < kDmWaves; w++) runs += S.wsum[w];
+        if (runs < kDmFewRuns) return;  // the candidate lists do such a tile faster
       }
     }
     for (uint32_t w = wave + 1; w < kDmWaves; w++) after = S.wmin[w] < after ? S.wmin[w] : after;
@@ -311,11 +316,11 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
       if (c0 < W) { extra_ip = c0; nR++; }
     }
     auto query_index = [&](uint32_t qi) -> uint32_t { return qi < nS ? S.others[qlo + qi] : extra_ip; };
-    {  // per query: its bucket, and the numbering of all bucket entries the queries will look at (two queries per thread)
-      uint32_t sz[2], sum = 0;
+    {  // per query: its bucket, and the numbering of all bucket entries the queries will look at (three queries per thread)
+      uint32_t sz[3], sum = 0;
 #pragma unroll
-      for (uint32_t k = 0; k < 2; k++) {
-        const uint32_t qi = tid * 2 + k;
+      for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t qi = tid * 3 + k;
         sz[k] = 0;
         if (qi < nR) {
           const uint32_t h = (px[query_index(qi)] * kSpMul) >> (32 - kSpPosBits);
@@ -338,13 +343,13 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
         return;
       }
 #pragma unroll
-      for (uint32_t k = 0; k < 2; k++) {
-        const uint32_t qi = tid * 2 + k;
+      for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t qi = tid * 3 + k;
         if (qi <= nR) S.qps[qi] = (uint16_t)at;  // qps[nR] = the total
         at += sz[k];
       }
     }
-    static_assert(kDmThreads * 2 >= kDmSub + 2 && kDmMaxVisits < 65536, "query scan");
+    static_assert(kDmThreads * 3 >= kDmSub + 2 && kDmMaxVisits < 65536, "query scan");
     __syncthreads();
     DM_PHASE_MARK(3);  // the stretch's queries numbered
     const uint32_t T = S.qps[nR];
@@ -362,24 +367,19 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
       q_first = lo_q;
     }
     {
-      uint32_t qi = q_first, next = 0, ip = 0, tag = 0, base = 0, local = 0;
-      bool fresh = true;
-      for (uint32_t w = w0; w < w1; w++) {
-        if (fresh || w >= next) {
-          if (!fresh && local) { atomicAdd(&S.qcnt2[qi >> 1], local << (16 * (qi & 1u))); local = 0; }
-          while (S.qps[qi + 1] <= w) qi++;
-          next = S.qps[qi + 1];
-          ip = query_index(qi);
-          tag = (px[ip] * kSpMul) << kSpTagShift;
-          base = (uint32_t)S.qbeg[qi] - S.qps[qi];
-          fresh = false;
+      uint32_t qi = q_first;
+      for (uint32_t w = w0; w < w1;) {
+        while (S.qps[qi + 1] <= w) qi++;
+        const uint32_t next = S.qps[qi + 1], stop = next < w1 ? next : w1;
+        const uint32_t ip = query_index(qi);
+        const uint32_t tag = (px[ip] * kSpMul) << kSpTagShift, base = (uint32_t)S.qbeg[qi] - S.qps[qi];
+        uint32_t local = 0;
+        for (; w < stop; w++) {
+          const uint32_t it = S.items[base + w], s = it & ((1u << kSpPosBits) - 1);
+          if (!((it ^ tag) >> kSpPosBits) && s < ip && s + kWindow >= ip) { hit |= 1ull << (w - w0); local++; }
         }
-        const uint32_t it = S.items[base + w], s = it & ((1u << kSpPosBits) - 1);
-        if ((it ^ tag) >> kSpPosBits || s >= ip || s + kWindow < ip) continue;
-        hit |= 1ull << (w - w0);
-        local++;
+        if (local) atomicAdd(&S.qcnt2[qi >> 1], local << (16 * (qi & 1u)));
       }
-      if (local) atomicAdd(&S.qcnt2[qi >> 1], local << (16 * (qi & 1u)));
     }
     DM_PHASE_MARK(4);  // the walk
     // The pairs found go into `pool` in the order of the visits, which is the order of the queries: every query's pairs
@@ -399,46 +399,44 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
         if (tid == 0) atomicAdd(&g_dm_reason[3], 1u);
         return;
       }
-      uint32_t cq[2], sum = 0;
+      uint32_t cq[3], sum = 0;
 #pragma unroll
-      for (uint32_t k = 0; k < 2; k++) {
-        const uint32_t qi = tid * 2 + k;
+      for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t qi = tid * 3 + k;
         cq[k] = qi < nR ? qcnt[qi] : 0u;
         sum += cq[k];
       }
       const uint32_t inq = wave_incl_scan_u32(sum, (int)lane);
       if (lane == 63) S.wsum3[wave] = inq;
       uint32_t qi = q_first, next = 0, base = 0;
-      bool fresh = true;
       uint64_t todo = hit;
       while (todo) {
         const uint32_t k = (uint32_t)__builtin_ctzll(todo);
         todo &= todo - 1;
         const uint32_t w = w0 + k;
-        if (fresh || w >= next) {
+        if (w >= next) {
           while (S.qps[qi + 1] <= w) qi++;
           next = S.qps[qi + 1];
           base = (uint32_t)S.qbeg[qi] - S.qps[qi];
-          fresh = false;
         }
-        S.pool[my_off++] = qi | ((S.items[base + w] & ((1u << kSpPosBits) - 1)) << 10);
+        S.pool[my_off++] = qi | ((S.items[base + w] & ((1u << kSpPosBits) - 1)) << 11);
       }
       __syncthreads();
       uint32_t at = inq - sum;
       for (uint32_t w = 0; w < wave; w++) at += S.wsum3[w];
 #pragma unroll
-      for (uint32_t k = 0; k < 2; k++) {
-        const uint32_t qk = tid * 2 + k;
+      for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t qk = tid * 3 + k;
         if (qk < nR) S.qoff[qk] = (uint16_t)at;
         at += cq[k];
       }
     }
-    static_assert(kDmSub + 2 <= (1u << 10), "a query's number fits ten bits of a pair");
+    static_assert(kDmSub + 2 <= (1u << 11), "a query's number fits eleven bits of a pair");
     DM_PHASE_MARK(5);  // the pairs listed (after waiting for the slowest walk)
     // the pairs: lcp of the source run's first pixel and the query (for the query's list and for its own match), and the
     // source aligned with the end of the query's own run (as k_lz77_sparse does it for tiles with runs)
     for (uint32_t j = tid; j < n_pairs; j += kDmThreads) {
-      const uint32_t pr = S.pool[j], qi = pr & 1023u, s = pr >> 10;
+      const uint32_t pr = S.pool[j], qi = pr & 2047u, s = pr >> 11;
       const uint32_t ip = query_index(qi);
       const uint32_t cap = W - ip < kMaxLen ? W - ip : kMaxLen;
       const uint32_t e = lcp_runs(s, ip, cap);
@@ -488,9 +486,9 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
     }
 
     DM_PHASE_MARK(8);  // own matches stored
-    // ---- the stretch's positions inside runs of v0, one per thread
-    const uint32_t ip = sa + tid;
-    if (ip < sb_ && px[ip] == v0) {
+    // ---- the stretch's positions inside runs of v0
+    for (uint32_t ip = sa + tid; ip < sb_; ip += kDmThreads) {
+      if (px[ip] != v0) continue;
       const uint32_t p = lo + ip;
       const uint32_t r = S.zr[ip], rs_own = S.rs[r], E = S.re[r];
       const uint32_t rem = M - p < kMaxLen ? M - p : kMaxLen;
@@ -542,16 +540,24 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
       }
       if (F < rem) {  // aligned sources: the list of the run's anchor (F < rem: the run ends inside the window, so it has one)
         const uint32_t qa = E < sb_ ? (uint32_t)S.qof[r] - qlo : nS, off = S.qoff[qa], cnt = qcnt[qa];
-        for (uint32_t i = 0; i < cnt; i++) {
-          const uint32_t ent = S.pool[off + i];
-          if (((ent >> 12) & 127u) < F) continue;
+        auto entry = [&](uint32_t ent) {
+          if (((ent >> 12) & 127u) < F) return;
           const uint32_t d = ip + F - (ent & ((1u << kSpPosBits) - 1));
           uint32_t l = F + (ent >> 19);
           l = l < d ? l : d;
           l = l < rem ? l : rem;
           const uint32_t kk = (l << 11) | d;
           key = kk > key ? kk : key;
+        };
+        uint32_t i = 0;
+        for (; i + 4 <= cnt; i += 4) {  // independent reads, four at a time
+          uint32_t ent[4];
+#pragma unroll
+          for (uint32_t u = 0; u < 4; u++) ent[u] = S.pool[off + i + u];
+#pragma unroll
+          for (uint32_t u = 0; u < 4; u++) entry(ent[u]);
         }
+        for (; i < cnt; i++) entry(S.pool[off + i]);
       }
       if (p == M - 1) key = 0;
       const uint32_t o = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_code_of(xsize, xinv, key & 2047u) << 19)) : 0u;
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(kDmThreads, 4) void k_lz77_dominant(const EncImage 
                                                                  const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
                                                                  const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                                                  uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile,
-                                                                 uint32_t *__restrict__ counter) {
+                                                                 uint32_t *__restrict__ counter, uint32_t take_flag) {
   __shared__ __attribute__((aligned(16))) DmShared S;
   __shared__ uint32_t s_chunk;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(kDmThreads, 4) void k_lz77_dominant(const EncImage 
       chunk = s_chunk;
       __syncthreads();  // everyone has read it before it is written again
       if (chunk >= ntiles) return ~0u;
-      waiting = __ballot(lane < kDmChunk && chunk + lane < ntiles && dense_tile[chunk + lane] == kTileExhaustive);
+      waiting = __ballot(lane < kDmChunk && chunk + lane < ntiles && dense_tile[chunk + lane] == take_flag);
     }
   };
   uint4 ahead[kDmLoads];
@@ -620,7 +626,7 @@ __global__ __launch_bounds__(kDmThreads, 4) void k_lz77_dominant(const EncImage 
     const DmGeo cur = geo;
     const uint32_t following = next_tile();  // (its barriers also make the window visible to everyone)
     if (following != ~0u) { geo = dm_geometry(imgs, st, sb_first, n, following); fetch_window(geo); }
-    if (cur.W) lz77_dominant_tile(S, cur, match, adv, dense_tile);
+    if (cur.W) lz77_dominant_tile(S, cur, match, adv, dense_tile, take_flag == 0);
     __syncthreads();  // the tile's shared memory is the next tile's
     tile = following;
   }
