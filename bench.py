@@ -271,6 +271,7 @@ def _encode_workload(args, world, rank, local_rank, dev, w, h, plan, workload, m
     total_px, elapsed = _timed_steps(args, world, dev, step, batch * npx)
     off, lens, status = res["r"]
     dense, tiles = enc.last_dense_tiles()
+    kinds = enc.last_tile_kinds()
     ok, decode = None, None
     bpp = 8.0 * float(lens.sum()) / (batch * npx)
     if not args.no_verify:
@@ -301,7 +302,7 @@ def _encode_workload(args, world, rank, local_rank, dev, w, h, plan, workload, m
     out = _base_line(args, world, metric, total_px / 1e6 / elapsed, elapsed, workload,
                      {"bits_per_pixel": bpp, "roundtrip_verified": ok, "decode": decode, "device_ms_per_step": 1e3 * dev_s,
                       "stage_ms_per_step": stage_ms, "roofline_stages": rows, "encode_bytes_per_pixel": sums,
-                      "exhaustive_search_tiles": {"tiles": dense, "of": tiles},
+                      "exhaustive_search_tiles": {"tiles": dense, "of": tiles}, "tile_kinds": kinds,
                       "roofline": {"kernel": "whole encode path", "bound": "hbm", "achieved": alg / dev_s / 1e9, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": alg / dev_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                    "algorithmic_bytes_per_launch": alg}})
@@ -350,8 +351,80 @@ def workload_predictor4k(args, world, rank, local_rank, dev):
                             "streams resident in HBM", predictor_bits=5)
 
 
+def workload_single512(args, world, rank, local_rank, dev):
+    """BASELINE configs[0]: one 512x512 image, encode + decode -- the case the reference's own CPU path runs.  Latency of one
+    call, through the host-memory entry points a caller of the reference would use (vp8l_encode / vp8l_decode: upload, kernels,
+    download, allocation of the result) and device-resident; the CPU port on one thread beside it (the reference is
+    single-threaded)."""
+    w = h = 512
+    npx = w * h
+    webp_amd.init()
+    d_in = torch.empty(npx, dtype=torch.int32, device=dev)
+    webp_amd.generate_device(3, w, h, 12345, 0, d_in.data_ptr(), device=local_rank)
+    img = d_in.cpu().numpy().view(np.uint32)
+    reps = max(5, args.steps * 5)
+
+    def timed(fn):
+        for _ in range(max(1, args.warmup)):
+            r = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / reps, r
+
+    enc_ms, stream = timed(lambda: webp_amd.encode(img, w, h))
+    dec_ms, dec = timed(lambda: webp_amd.decode(stream))
+    ok = bool(np.array_equal(dec[0], img))
+    enc = webp_amd.Encoder(local_rank)
+    cap = enc.bound(w, h)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    e_dev_ms, res = timed(lambda: enc.encode_device([d_in.data_ptr()], [w], [h], d_out.data_ptr(), cap))
+    e_dev_kernels = 1e3 * enc.last_device_seconds()
+    off, lens, st = res
+    dec_ctx = webp_amd.Decoder(local_rank)
+    d_dec = torch.empty(npx, dtype=torch.int32, device=dev)
+    dargs = _decode_args([d_out.data_ptr() + int(off[0])], [int(lens[0])], [w], [h], [d_dec.data_ptr()])
+    d_dev_ms, st2 = timed(lambda: dec_ctx.decode_device(*dargs))
+    d_dev_kernels = 1e3 * dec_ctx.last_device_seconds()
+    ok = ok and bool(st2[0] == 0 and torch.equal(d_dec, d_in))
+    total_ms = enc_ms + dec_ms
+    out = _base_line(args, world, "vp8l_encode_plus_decode_megapixels_per_sec", 2 * npx / 1e6 / (total_ms * 1e-3), total_ms * 1e-3 * args.steps,
+                     "one synthetic 512x512 image, VP8L encode then decode, one call each through vp8l_encode / vp8l_decode from and to host "
+                     "memory (BASELINE configs[0]); mean of %d calls" % reps,
+                     {"bits_per_pixel": 8.0 * len(stream) / npx, "roundtrip_verified": ok,
+                      "encode_ms": enc_ms, "decode_ms": dec_ms,
+                      "device_resident": {"encode_ms": e_dev_ms, "decode_ms": d_dev_ms, "encode_kernels_ms": e_dev_kernels, "decode_kernels_ms": d_dev_kernels},
+                      "reference_cpu_one_thread_ms": {"encode": 131.0, "decode": 6.3,
+                                                      "source": "the reference's own encoder and decoder compiled with its flags, survey container (not this box)"}})
+    out["ms_per_step"] = total_ms
+    out["cpu_baseline"] = None
+    if world == 1 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle as O
+        O.lib()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            rc, data = O.encode(img, w, h)
+        t1 = time.perf_counter()
+        for _ in range(10):
+            rc2 = O.decode(data)[0]
+        t2 = time.perf_counter()
+        assert rc == 0 and rc2 == 0 and data == stream
+        pe, pd = 1e3 * (t1 - t0) / 3, 1e3 * (t2 - t1) / 10
+        out["cpu_baseline"] = {"value": 2 * npx / 1e6 / ((pe + pd) * 1e-3), "unit": "MP/s", "cores": 1, "kind": "port", "encode_ms": pe, "decode_ms": pd,
+                               "sample": "the same image, encode (3 calls) and decode (10 calls) on one host thread"}
+    return out
+
+
 OTHER_WORKLOADS = {"decode1080p": workload_decode1080p, "palette2k": workload_palette2k, "single16k": workload_single16k,
-                   "predictor4k": workload_predictor4k}
+                   "predictor4k": workload_predictor4k, "single512": workload_single512}
+# what the default run adds to its line under "configs": BASELINE's other configurations, a few steps each
+CONFIG_RUNS = (("configs[0] single512", "single512"), ("configs[2] single16k", "single16k"), ("configs[3] decode1080p", "decode1080p"),
+               ("configs[4] palette2k", "palette2k"), ("predictor4k", "predictor4k"))
+CONFIG_KEYS = ("metric", "value", "unit", "ms_per_step", "bits_per_pixel", "roundtrip_verified", "device_ms_per_step", "stage_ms_per_step",
+               "exhaustive_search_tiles", "tile_kinds", "encode_ms", "decode_ms", "device_resident", "reference_cpu_one_thread_ms", "cpu_baseline")
 
 
 def host_to_host(local_rank, d_in, w, h, images):
@@ -523,6 +596,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="the headline workload only: leave BASELINE's other configurations out of the line")
     ap.add_argument("--workload", default="encode4k", choices=sorted(OTHER_WORKLOADS) + ["encode4k"],
                     help="encode4k = BASELINE configs[1] (the headline line); the others measure configs[2..4]")
     args = ap.parse_args()
@@ -550,6 +624,29 @@ def main():
     dev = torch.device("cuda", local_rank)
     fn = workload_encode4k if args.workload == "encode4k" else OTHER_WORKLOADS[args.workload]
     out = fn(args, world, rank, local_rank, dev)
+    if args.workload == "encode4k" and world == 1 and not args.no_configs:
+        # BASELINE's other configurations in the same line (each with its own timed steps; `value` stays configs[1]'s)
+        out["configs"] = {}
+        for label, name in CONFIG_RUNS:
+            torch.cuda.empty_cache()
+            sub = argparse.Namespace(**vars(args))
+            sub.steps, sub.warmup, sub.workload = 3, 1, name
+            sub.no_cpu = args.no_cpu or name != "single512"
+            try:
+                r = OTHER_WORKLOADS[name](sub, world, rank, local_rank, dev)
+            except Exception as exc:  # a failing extra must not take the headline figure with it
+                out["configs"][label] = {"error": repr(exc)}
+                continue
+            ent = {k: r[k] for k in CONFIG_KEYS if k in r}
+            ent["workload"] = r["config"]["workload"]
+            if r.get("decode"):
+                ent["decode_value"] = r["decode"]["value"]
+            if "predictor_variant" in r:
+                ent["predictor_variant"] = {k: r["predictor_variant"][k] for k in ("value", "ms_per_step", "bits_per_pixel", "roundtrip_verified",
+                                                                                      "stage_ms_per_step", "exhaustive_search_tiles")}
+                if r["predictor_variant"].get("decode"):
+                    ent["predictor_variant"]["decode_value"] = r["predictor_variant"]["decode"]["value"]
+            out["configs"][label] = ent
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

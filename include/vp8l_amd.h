@@ -190,7 +190,8 @@ int vp8l_decoder_decode_device(vp8l_decoder *dec, size_t n, const uint8_t *const
 /* VP8L_DEC_OPT_WHOLE_DEVICE: streams are cut into segments of 65536 bits that many workgroups decode (a scout per
  * segment records its tokens, a serial check accepts them, pointer jumping over the pixels resolves the references; a
  * 3840x2160 stream in 3 ms instead of half a second, 29 GP/s instead of 4.2 for a large batch).  0 (default) = when a
- * call has at least 2 MiB of streams; 1 = never; 2 = always.  Images below 65536 pixels, streams with a colour cache,
+ * call has at least 2 MiB of streams, or at least 48 KiB of them in streams of 32 KiB and more on average (one 512x512
+ * photo-like stream: 1.5 instead of 3.5 ms); 1 = never; 2 = always.  Images below 65536 pixels, streams with a colour cache,
  * several Huffman groups or tokens the segment decoder does not take are decoded by one workgroup each as before.
  * Workspace: 16 bytes per stream byte and 4 bytes per pixel, in passes of at most 2 GiB of streams.  Identical pixels
  * and verdicts. */

@@ -713,7 +713,9 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
                                                  const uint32_t *__restrict__ sb_first, uint32_t n, const uint32_t tile,
                                                  uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                                  uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile, uint32_t tune_mean_bucket,
-                                                 uint32_t tune_budget, uint32_t tune_max_bucket) {
+                                                 uint32_t tune_budget, uint32_t tune_max_bucket, uint32_t *__restrict__ given_up) {
+  // given_up: counts the tiles left to the exhaustive kernel (a wave that gives up alone counts for itself: an upper bound)
+  // (the top bit of tune_mean_bucket: k_lz77_dominant has looked at the tiles first, and the ones it searched are to be skipped)
   __shared__ __attribute__((aligned(16))) uint32_t px[kSpSources + kMaxLen + 4];
   // Tiles with runs: runlen[i] = pixels equal to pixel i from there on (within the window), 16 bits each.  Tiles without
   // runs use the same memory per wave: the best match so far of the 128 positions the wave is working on and a queue of
@@ -740,7 +742,8 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
   const uint32_t W = hi - lo;
   const uint64_t pos0 = imgs[img].pos0;
   if (PAIRS_KERNEL && dense_tile[(pos0 + a) / kLzTile] != kTilePairs) return;
-  if (!PAIRS_KERNEL && dense_tile[(pos0 + a) / kLzTile] == kTileDoneDominant) return;  // (only when that kernel ran first)
+  if (!PAIRS_KERNEL && (tune_mean_bucket >> 31) && dense_tile[(pos0 + a) / kLzTile] == kTileDoneDominant) return;  // (that kernel ran first)
+  tune_mean_bucket &= 0x7fffffffu;
   const uint32_t *data = pix + pos0;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   VP8L_PHASE_BEGIN();
@@ -848,7 +851,7 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
   if (mx > tune_max_bucket) s_abort = 1;
   if (mx >= kSpHeavyBucket) s_heavy = 1;
   __syncthreads();
-  if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; return; }
+  if (s_abort) { if (tid == 0) { dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; atomicAdd(given_up, 1u); } return; }
   uint32_t run = incl - sum;
   for (uint32_t k = 0; k < wave; k++) run += wsum[k];
   uint32_t entries = 0;  // of all buckets (counted for tiles with a full bucket only)
@@ -866,7 +869,7 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
     if (lane == 0 && sq) atomicAdd(&s_sumsq, sq);
     __syncthreads();
     for (uint32_t k = 0; k < kSpWaves; k++) entries += wsum[k];
-    if (s_sumsq > tune_mean_bucket * entries) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; return; }
+    if (s_sumsq > tune_mean_bucket * entries) { if (tid == 0) { dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; atomicAdd(given_up, 1u); } return; }
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -1101,7 +1104,7 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
         else { open_positions[2] = still_open[0]; open_positions[3] = still_open[1]; }
       }
       if (__ballot(spent > tune_budget)) {  // too much work for this form: the exhaustive kernel redoes the tile
-        if (lane == 0) dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive;
+        if (lane == 0) { dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; atomicAdd(given_up, 1u); }
         return true;
       }
     }
@@ -1239,7 +1242,7 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
   if (over) s_abort = 1;
   __syncthreads();
   VP8L_PHASE_MARK(5);  // waiting for the other waves
-  if (s_abort) { if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; return; }
+  if (s_abort) { if (tid == 0) { dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; atomicAdd(given_up, 1u); } return; }
 #pragma unroll
   for (uint32_t k = 0; k < kSpTile / kSpThreads; k++) {
     const uint32_t p = a + k * kSpThreads + tid;
@@ -1255,13 +1258,13 @@ __global__ __launch_bounds__(kSpThreads) void k_lz77_sparse(const EncImage *__re
                                                      const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
                                                      uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                                      uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile, uint32_t tune_mean_bucket,
-                                                     uint32_t tune_budget, uint32_t tune_max_bucket) {
+                                                     uint32_t tune_budget, uint32_t tune_max_bucket, uint32_t *__restrict__ given_up) {
   // Workgroups go round-robin to the 8 XCDs, each with its own L2.  Neighbouring tiles share half of their
   // window, so every XCD takes one contiguous eighth of the tiles: the overlap is then read from its L2, not twice from HBM.
   const uint32_t per_xcd = gridDim.x / 8;  // the grid is a multiple of 8
   const uint32_t tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (tile >= ntiles) return;
-  lz77_sparse_tile<false>(imgs, st, sb_first, n, tile, pix, match, adv, dense_tile, tune_mean_bucket, tune_budget, tune_max_bucket);
+  lz77_sparse_tile<false>(imgs, st, sb_first, n, tile, pix, match, adv, dense_tile, tune_mean_bucket, tune_budget, tune_max_bucket, given_up);
 }
 
 // The tiles that k_lz77_sparse marked kTilePairs (it has stored their residual already).  Often there are none, and a
@@ -1272,7 +1275,7 @@ __global__ __launch_bounds__(kSpThreads, 8) void k_lz77_pairs(const EncImage *__
                                                     const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
                                                     uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                                     uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile, uint32_t tune_mean_bucket,
-                                                    uint32_t tune_budget, uint32_t tune_max_bucket) {
+                                                    uint32_t tune_budget, uint32_t tune_max_bucket, uint32_t *__restrict__ given_up) {
   // 64 of the workgroup's tiles at a time: every lane looks at one flag, then the marked ones are done one after the other
   for (uint32_t base = blockIdx.x; base < ntiles; base += 64 * gridDim.x) {
     const uint32_t mine = base + (threadIdx.x & 63u) * gridDim.x;
@@ -1280,7 +1283,7 @@ __global__ __launch_bounds__(kSpThreads, 8) void k_lz77_pairs(const EncImage *__
     while (marked) {
       const uint32_t k = (uint32_t)__builtin_ctzll(marked);
       marked &= marked - 1;
-      lz77_sparse_tile<true>(imgs, st, sb_first, n, base + k * gridDim.x, pix, match, adv, dense_tile, tune_mean_bucket, tune_budget, tune_max_bucket);
+      lz77_sparse_tile<true>(imgs, st, sb_first, n, base + k * gridDim.x, pix, match, adv, dense_tile, tune_mean_bucket, tune_budget, tune_max_bucket, given_up);
       __syncthreads();  // the tile's shared memory is the next tile's
     }
   }
@@ -2228,14 +2231,14 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
     const bool dominant_first = pred != 0 && (g_tune[3] & 1u);
     if (dominant_first)
       hipLaunchKernelGGL(k_lz77_dominant, dim3(dm_grid), dim3(kDmThreads), 0, s, B.imgs, B.st, B.sbf, nl, gsb * (kSuper / kSpTile), B.pix, B.match,
-                         B.adv8, B.dense, dm_counter, 0u);
+                         B.adv8, B.dense, dm_counter, 0u, (const uint32_t *)nullptr);
     hipLaunchKernelGGL(k_lz77_sparse, dim3((gsb * (kSuper / kSpTile) + 7) / 8 * 8), dim3(kSpThreads), 0, s, B.imgs, B.st, B.sbf, nl,
-                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0], g_tune[1], tune_max_bucket);
+                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0] | (dominant_first ? 0x80000000u : 0u), g_tune[1], tune_max_bucket, dm_counter + 2);
     hipLaunchKernelGGL(k_lz77_pairs, dim3(std::min<uint32_t>(gsb * (kSuper / kSpTile), kSpPairsGrid)), dim3(kSpThreads), 0, s, B.imgs, B.st, B.sbf, nl,
-                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0], g_tune[1], tune_max_bucket);
+                       gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, g_tune[0], g_tune[1], tune_max_bucket, dm_counter + 2);
     if (g_tune[3] & 1u)  // what the candidate lists gave up on (after a first look: what that left them and they could not do either)
       hipLaunchKernelGGL(k_lz77_dominant, dim3(dm_grid), dim3(kDmThreads), 0, s, B.imgs, B.st, B.sbf, nl, gsb * (kSuper / kSpTile), B.pix, B.match,
-                         B.adv8, B.dense, dm_counter + 1, (uint32_t)kTileExhaustive);
+                         B.adv8, B.dense, dm_counter + 1, (uint32_t)kTileExhaustive, (const uint32_t *)(dm_counter + 2));
   }
   mark(9);  // also when the candidate-list kernel is switched off
   hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,

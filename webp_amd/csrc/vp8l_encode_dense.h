@@ -583,10 +583,16 @@ __global__ __launch_bounds__(kDmThreads, 4) void k_lz77_dominant(const EncImage 
                                                                  const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
                                                                  const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
                                                                  uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile,
-                                                                 uint32_t *__restrict__ counter, uint32_t take_flag) {
+                                                                 uint32_t *__restrict__ counter, uint32_t take_flag,
+                                                                 const uint32_t *__restrict__ waiting_tiles) {
   __shared__ __attribute__((aligned(16))) DmShared S;
   __shared__ uint32_t s_chunk;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
+  // waiting_tiles (may be null): an upper bound of the tiles with the flag, counted by the kernel that set it.  None: nothing
+  // to do (a look at a million flags of a batch that needs none of this took 0.76 ms); few: the flags are looked at 64 at a time
+  const uint32_t n_waiting = waiting_tiles ? *waiting_tiles : ntiles;
+  if (n_waiting == 0) return;
+  const uint32_t chunk_tiles = (uint64_t)n_waiting * 8 > ntiles ? kDmChunk : 64u;
   uint32_t chunk = 0;
   uint64_t waiting = 0;  // tiles of the chunk that are still to do (the same in every thread)
   // the next waiting tile, or ~0u when the counter has run past the last tile; called by all threads
@@ -597,12 +603,12 @@ __global__ __launch_bounds__(kDmThreads, 4) void k_lz77_dominant(const EncImage 
         waiting &= waiting - 1;
         return chunk + k;
       }
-      if (tid == 0) s_chunk = atomicAdd(counter, kDmChunk);
+      if (tid == 0) s_chunk = atomicAdd(counter, chunk_tiles);
       __syncthreads();
       chunk = s_chunk;
       __syncthreads();  // everyone has read it before it is written again
       if (chunk >= ntiles) return ~0u;
-      waiting = __ballot(lane < kDmChunk && chunk + lane < ntiles && dense_tile[chunk + lane] == take_flag);
+      waiting = __ballot(lane < chunk_tiles && chunk + lane < ntiles && dense_tile[chunk + lane] == take_flag);
     }
   };
   uint4 ahead[kDmLoads];
