@@ -33,3 +33,11 @@ if hasattr(L, "vp8l_debug_dominant_phase_cycles"):
              "wait for pairs", "own matches", "v0 positions", "wait for v0 positions", "-"]
     tot = float(sum(ph)) or 1.0
     print("phases:", ", ".join("%s %.1f%%" % (n, 100.0 * c / tot) for n, c in zip(names, ph) if c))
+if hasattr(L, "vp8l_debug_grams_phase_cycles"):
+    ph = (C.c_ulonglong * 12)()
+    L.vp8l_debug_grams_phase_cycles(ph)
+    enc.encode_device([d_in.data_ptr()], [w], [h], d_out.data_ptr(), cap)
+    L.vp8l_debug_grams_phase_cycles(ph)
+    names = ["words numbered", "grams numbered", "lists", "search 16", "search 4", "search 2", "search 1", "wait 16", "wait 4", "wait 2", "wait 1", "-"]
+    tot = float(sum(ph)) or 1.0
+    print("grams phases:", ", ".join("%s %.1f%%" % (n, 100.0 * c / tot) for n, c in zip(names, ph) if c))

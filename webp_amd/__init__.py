@@ -323,7 +323,8 @@ class Encoder:
             raise Vp8lError(rc, "vp8l_encoder_set_option")
 
     def set_match_search(self, mode):
-        """0 (default): candidate lists first; 1: exhaustive everywhere; 2: the candidate lists refuse every tile (same matches)."""
+        """0 (default): candidate lists first; 1: exhaustive everywhere; 2: the candidate lists refuse every tile; 3: as 2, with the
+        search by numbered grams in front of the exhaustive one (same matches every way)."""
         rc = lib().vp8l_encoder_set_option(self._h, 1, int(mode))
         if rc != OK:
             raise Vp8lError(rc, "vp8l_encoder_set_option")

@@ -2142,7 +2142,8 @@ struct vp8l_encoder {
   // workspace (grown on demand)
   DeviceBuffer d_imgs, d_state, d_sbfirst, d_gsets, d_pix, d_match, d_flags, d_histo, d_tables, d_sx, d_entry,
       d_unit_bits, d_unit_off, d_dense, d_group_bits, d_adv, d_pix2, d_modes, d_elems;
-  int match_mode = 0;  // 0 = candidate lists with the other forms behind them, 1 = exhaustive only, 2 = the candidate lists give up on every tile (verification of what comes behind them)
+  int match_mode = 0;  // 0 = candidate lists with the other forms behind them, 1 = exhaustive only, 2 = the candidate lists give up on every tile
+                       // (verification of what comes behind them), 3 = the same with k_lz77_grams between k_lz77_dominant and the exhaustive kernel
   const uint32_t *last_pix = nullptr;  // coded pixels of the last call (for fetch_stage)
   bool last_pred = false;
   bool last_cross = false;
@@ -2163,7 +2164,7 @@ struct vp8l_encoder {
 };
 
 // Heuristics of the candidate-list kernel (when a tile goes to the exhaustive kernel instead); VP8L_TUNE="mean_bucket,budget,max_bucket,dense"
-// overrides them for measurements (dense: bit 0 = k_lz77_dominant runs; every setting gives the same matches).
+// overrides them for measurements (dense: bit 0 = k_lz77_dominant runs, bit 1 = with its part for grams; every setting gives the same matches).
 static uint32_t g_tune[4] = {kSpMaxMeanBucket, kSpBudget, kSpMaxBucket, 1};
 static const bool g_tune_read = [] {
   const char *v = getenv("VP8L_TUNE");
@@ -2196,8 +2197,9 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
                                  int match_mode, uint8_t *d_out, hipEvent_t *ev, uint32_t standard = 0, const ExtArgs *extp = nullptr,
                                  uint32_t meta_bits = 0) {
   // match_mode 2: the candidate lists refuse every tile (no bucket may hold anything), so that the forms behind them see all tiles
-  const uint32_t tune_max_bucket = match_mode == 2 ? 0u : g_tune[2];
-  if (match_mode == 2) match_mode = 0;
+  const uint32_t tune_max_bucket = match_mode >= 2 ? 0u : g_tune[2];
+  const bool with_grams = match_mode == 3 || (g_tune[3] & 2u);
+  if (match_mode >= 2) match_mode = 0;
   bool h = true;
   h = h && hip_ok(hipMemsetAsync(B.st, 0, nl * sizeof(EncState), s), "clear state");
   h = h && hip_ok(hipMemsetAsync(B.gsets, 0xff, (size_t)nl * kSetSlots * sizeof(unsigned long long), s), "clear sets");
@@ -2239,6 +2241,11 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
     if (g_tune[3] & 1u)  // what the candidate lists gave up on (after a first look: what that left them and they could not do either)
       hipLaunchKernelGGL(k_lz77_dominant, dim3(dm_grid), dim3(kDmThreads), 0, s, B.imgs, B.st, B.sbf, nl, gsb * (kSuper / kSpTile), B.pix, B.match,
                          B.adv8, B.dense, dm_counter + 1, (uint32_t)kTileExhaustive, (const uint32_t *)(dm_counter + 2));
+    // ... and what has no frequent value either: exact, but two to four times slower than the exhaustive kernel on the bundled palettes
+    // it was made for (its lists are chains of dependent reads), so only on request
+    if (with_grams)
+      hipLaunchKernelGGL(k_lz77_grams, dim3(dm_grid), dim3(kDmThreads), 0, s, B.imgs, B.st, B.sbf, nl, gsb * (kSuper / kSpTile), B.pix, B.match,
+                         B.adv8, B.dense, dm_counter + 3, (const uint32_t *)(dm_counter + 2));
   }
   mark(9);  // also when the candidate-list kernel is switched off
   hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,
@@ -2550,7 +2557,7 @@ extern "C" double vp8l_encoder_last_device_seconds(const vp8l_encoder *e) { retu
 extern "C" int vp8l_encoder_set_option(vp8l_encoder *e, int option, int value) {
   if (!e) return VP8L_ERR_BAD_ARGUMENT;
   std::lock_guard<std::mutex> lock(e->mu);
-  if (option == VP8L_OPT_MATCH_SEARCH && value >= 0 && value <= 2) { e->match_mode = value; return VP8L_OK; }
+  if (option == VP8L_OPT_MATCH_SEARCH && value >= 0 && value <= 3) { e->match_mode = value; return VP8L_OK; }
   if (option == VP8L_OPT_PREDICTOR_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->pred_bits = value; return VP8L_OK; }
   if (option == VP8L_OPT_CROSS_COLOR_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->cross_bits = value; return VP8L_OK; }
   if (option == VP8L_OPT_STANDARD && (value == 0 || value == 1)) { e->standard = value != 0; return VP8L_OK; }
@@ -2798,6 +2805,13 @@ extern "C" int vp8l_debug_dominant_phase_cycles(unsigned long long *out12) {
   if (!hip_ok(hipMemcpyFromSymbol(out12, HIP_SYMBOL(vp8l::g_dm_phase), 12 * sizeof(unsigned long long)), "read phase counters")) return VP8L_ERR_HIP;
   unsigned long long zero[12] = {};
   if (!hip_ok(hipMemcpyToSymbol(HIP_SYMBOL(vp8l::g_dm_phase), zero, sizeof(zero)), "clear phase counters")) return VP8L_ERR_HIP;
+  return VP8L_OK;
+}
+extern "C" int vp8l_debug_grams_phase_cycles(unsigned long long *out12) {
+  if (!hip_ok(hipDeviceSynchronize(), "sync")) return VP8L_ERR_HIP;
+  if (!hip_ok(hipMemcpyFromSymbol(out12, HIP_SYMBOL(vp8l::g_gm_phase), 12 * sizeof(unsigned long long)), "read phase counters")) return VP8L_ERR_HIP;
+  unsigned long long zero[12] = {};
+  if (!hip_ok(hipMemcpyToSymbol(HIP_SYMBOL(vp8l::g_gm_phase), zero, sizeof(zero)), "clear phase counters")) return VP8L_ERR_HIP;
   return VP8L_OK;
 }
 extern "C" int vp8l_debug_phase_cycles(unsigned long long *out8) {

@@ -111,7 +111,7 @@ constexpr uint32_t kDmLoads = (kDmMaxW + 4 * kDmThreads - 1) / (4 * kDmThreads);
 // The tile's window must be in S.px (dm_commit_window) before the call.
 // first_look: the candidate lists have not seen the tile yet and take it if it is left (then only tiles with many runs of the
 // frequent value are searched here).
-__device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, uint32_t *__restrict__ match,
+__device__ __forceinline__ bool lz77_dominant_tile(DmShared &S, const DmGeo &G, uint32_t *__restrict__ match,
                                                    uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile, bool first_look) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t M = G.M, xsize = G.xsize, xinv = G.xinv, a = G.a, b = G.b, lo = G.lo, W = G.W;
@@ -141,7 +141,7 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
     }
     if ((best >> 6) < 6) {  // no value holds a tenth of the samples: the tile stays with the exhaustive kernel
       if (tid == 0) atomicAdd(&g_dm_reason[0], 1u);
-      return;
+      return false;
     }
     v0 = (uint32_t)__shfl((int)smp, (int)(63u - (best & 63u)), 64);
   }
@@ -186,12 +186,12 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
       for (uint32_t w = 0; w < kDmWaves; w++) starts += S.wsum2[w];
       if (starts > kDmMaxStarts) {  // (the same in every thread)
         if (tid == 0) atomicAdd(&g_dm_reason[1], 1u);
-        return;
+        return false;
       }
       if (first_look) {
         uint32_t runs = 0;
         for (uint32_t w = 0; w < kDmWaves; w++) runs += S.wsum[w];
-        if (runs < kDmFewRuns) return;  // the candidate lists do such a tile faster
+        if (runs < kDmFewRuns) return false;  // the candidate lists do such a tile faster
       }
     }
     for (uint32_t w = wave + 1; w < kDmWaves; w++) after = S.wmin[w] < after ? S.wmin[w] : after;
@@ -340,7 +340,7 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
       if (total > kDmMaxVisits) {  // (every thread sees the same total) too much to look at
         if (sub > kDmMinSub) { sub >>= 1; __syncthreads(); continue; }
         if (tid == 0) atomicAdd(&g_dm_reason[2], 1u);
-        return;
+        return false;
       }
 #pragma unroll
       for (uint32_t k = 0; k < 3; k++) {
@@ -397,7 +397,7 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
       if (n_pairs > kDmPool) {  // (the same in every thread)
         if (sub > kDmMinSub) { sub >>= 1; __syncthreads(); continue; }
         if (tid == 0) atomicAdd(&g_dm_reason[3], 1u);
-        return;
+        return false;
       }
       uint32_t cq[3], sum = 0;
 #pragma unroll
@@ -571,6 +571,220 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
     if (((sa - ia) & (kDmSub - 1)) == 0) sub = kDmSub;  // back to whole stretches at their borders
   }
   if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = kTileDoneDominant;
+  return true;
+}
+
+// =============================================================================================================
+// k_lz77_grams' part: tiles without a frequent value but with few values that repeat everywhere (palette indices
+// bundled into words).  Half of the positions of such tiles have matches of 128 words, the others of 2 to 15, and
+// 30 to 110 of the 1024 sources start with the position's word: lists of single words are long, and comparing word
+// by word is slow.  Here the sources are numbered by what follows them: id1[i] numbers the word at i (equal numbers,
+// equal words), id2[i] the pair of words at i, then id4, id8, id16 -- each from the pair (id[i], id[i + half]) of the
+// level below, through an exact table (the pair is the key, compared in full; the number is its slot).  Then
+//   * lcp(q, p) takes steps of 16, then 4, then 1 (at most 14 comparisons for 128 words);
+//   * the sources of a position are looked up by the longest gram first: the list of sources with the position's
+//     16-gram holds every source that matches for 16 words or more, so if the best of them (scored in full) reaches 16,
+//     nothing else need be looked at; else the list of its 4-gram, with the same argument for 4; then pairs; and what is
+//     still open then matches for one word at best, where the farthest source of the word wins (lz77.h:68).
+// Positions that a level settles leave; the others are collected for the next level.
+// =============================================================================================================
+constexpr uint32_t kGmSlots = 8192;          // slots of the table that numbers the grams of a level (at most kDmMaxW are used)
+constexpr uint32_t kGmEmpty = 0xffffffffu;
+constexpr uint32_t kGmNone = 0xffffu;        // end of a list
+constexpr uint32_t kGmUndefined = kGmSlots;  // numbers from here on: a gram that reaches past the window's end (each one its own)
+constexpr uint32_t kGmBudget = 6000;         // list entries + comparisons one thread may spend on its positions
+constexpr uint8_t kTileDoneGrams = 5;        // tile flag: searched here
+static_assert(kGmUndefined + kDmMaxW < 65536, "numbers fit 16 bits");
+
+#ifdef VP8L_PHASE_TIMING
+__device__ unsigned long long g_gm_phase[12];
+#define GM_PHASE_MARK(k)                                                       \
+  do {                                                                          \
+    const unsigned long long gm_n = __builtin_readcyclecounter();               \
+    if (threadIdx.x == 0) atomicAdd(&g_gm_phase[k], gm_n - gm_t);               \
+    gm_t = gm_n;                                                                \
+  } while (0)
+#define GM_PHASE_BEGIN() unsigned long long gm_t = __builtin_readcyclecounter()
+#else
+#define GM_PHASE_MARK(k) do {} while (0)
+#define GM_PHASE_BEGIN() do {} while (0)
+#endif
+
+struct GmShared {
+  union {
+    uint32_t px[kDmMaxW];              // the window (until the words are numbered)
+    struct {
+      uint32_t keys[kDmTile];          // per position of the tile: best match so far, length << 11 | distance
+      uint16_t todo0[kDmTile];         // positions (window indices) still open: the list of the levels 16 and 2
+    } s;
+  };
+  uint32_t table[kGmSlots];            // numbering a level: the keys; searching a level: per number the first source of its list
+  uint16_t id1[kDmMaxW], id4[kDmMaxW];
+  uint16_t idx[kDmMaxW];               // id2 while id4 is made from it, id16 for the search of that level, id2 again for the search of pairs
+  uint16_t next[kDmMaxW];              // numbering: id8; searching: the next source of the same list
+  uint16_t todo1[kDmTile];             // ... the list of the levels 4 and 1
+  uint32_t n_open[2];
+  uint32_t abort_flag;
+};
+static_assert(sizeof(GmShared) + 64 <= 80 * 1024 && sizeof(DmShared) + 64 <= 80 * 1024, "two workgroups share a CU's 160 KB");
+
+// number of `key` in the table (inserted if new); keys are below kGmEmpty
+__device__ __forceinline__ uint32_t gm_number(uint32_t *table, uint32_t key) {
+  uint32_t slot = (key * 0x9E3779B1u) >> (32 - 13);
+  for (;;) {
+    const uint32_t old = atomicCAS(&table[slot], kGmEmpty, key);
+    if (old == kGmEmpty || old == key) return slot;
+    slot = (slot + 1) & (kGmSlots - 1);
+  }
+}
+
+__device__ __forceinline__ bool lz77_grams_tile(GmShared &S, const DmGeo &G, uint32_t *__restrict__ match,
+                                                uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t M = G.M, xsize = G.xsize, xinv = G.xinv, a = G.a, b = G.b, lo = G.lo, W = G.W;
+  const uint64_t pos0 = G.pos0;
+  const uint32_t ia = a - lo, ib = b - lo;
+  GM_PHASE_BEGIN();
+  // ---- numbering: words, then pairs of numbers, level by level
+  for (uint32_t i = tid; i < kGmSlots; i += kDmThreads) S.table[i] = kGmEmpty;
+  if (tid == 0) { S.abort_flag = 0; S.n_open[0] = 0; S.n_open[1] = 0; }
+  __syncthreads();
+  for (uint32_t i = tid; i < W; i += kDmThreads) {
+    const uint32_t v = S.px[i];
+    // (a word equal to the empty mark is numbered under another key that no word has twice: its own complement's slot is as good as any)
+    S.id1[i] = (uint16_t)gm_number(S.table, v == kGmEmpty ? 0xfffffffeu : v);
+  }
+  __syncthreads();
+  // a word 0xfffffffe and a word 0xffffffff would share a number: tell them apart again (both in one window: never seen, but exactness)
+  // -- by giving every 0xffffffff the undefined number of its place when a 0xfffffffe exists is not exact either; so such a tile is left
+  {
+    bool clash = false;
+    for (uint32_t i = tid; i < W; i += kDmThreads) clash |= S.px[i] == kGmEmpty;
+    if (__syncthreads_or(clash)) {
+      bool other = false;
+      for (uint32_t i = tid; i < W; i += kDmThreads) other |= S.px[i] == 0xfffffffeu;
+      if (__syncthreads_or(other)) return false;  // (the same in every thread)
+    }
+  }
+  auto level_up = [&](const uint16_t *from, uint16_t *to, uint32_t half) {  // to[i] numbers (from[i], from[i + half])
+    for (uint32_t i = tid; i < kGmSlots; i += kDmThreads) S.table[i] = kGmEmpty;
+    __syncthreads();
+    for (uint32_t i = tid; i < W; i += kDmThreads) {
+      uint32_t id = kGmUndefined + i;
+      if (i + half < W) {
+        const uint32_t x = from[i], y = from[i + half];
+        if (x < kGmUndefined && y < kGmUndefined) id = gm_number(S.table, (x << 13) | y);
+      }
+      to[i] = (uint16_t)id;
+    }
+    __syncthreads();
+  };
+  GM_PHASE_MARK(0);  // words numbered
+  level_up(S.id1, S.idx, 1);    // id2, on the way to id4 (made again when the search gets to pairs)
+  level_up(S.idx, S.id4, 2);
+  level_up(S.id4, S.next, 4);   // id8, only on the way to id16
+  level_up(S.next, S.idx, 8);   // id16
+  GM_PHASE_MARK(1);  // grams numbered
+  // (the window's words are not needed any more: every comparison is one of numbers) -- their memory holds the keys from here on
+  for (uint32_t t = tid; t < kDmTile; t += kDmThreads) {
+    S.s.keys[t] = 0;
+    if (ia + t < ib) S.s.todo0[t] = (uint16_t)(ia + t);
+  }
+  uint32_t n_open = ib - ia;
+  uint32_t spent = 0;
+  bool have16 = true;
+  auto lcp = [&](uint32_t q, uint32_t ip, uint32_t cap) {
+    uint32_t l = 0;
+    // (steps of 16 only while the 16-grams are there: on the later levels no match reaches 16)
+    while (have16 && l + 16 <= cap && S.idx[q + l] == S.idx[ip + l]) { l += 16; spent++; }
+    while (l + 4 <= cap && S.id4[q + l] == S.id4[ip + l]) { l += 4; spent++; }
+    while (l < cap && S.id1[q + l] == S.id1[ip + l]) { l++; spent++; }
+    return l;
+  };
+  const uint32_t nsrc = ib;  // sources: window indices below the tile's end
+  uint32_t cur = 0;
+#pragma unroll 1
+  for (uint32_t level = 0; level < 4; level++) {
+    const uint16_t *ids = level == 0 ? S.idx : level == 1 ? S.id4 : level == 2 ? S.idx : S.id1;
+    const uint32_t L = level == 0 ? 16u : level == 1 ? 4u : level == 2 ? 2u : 1u;
+    if (level == 1) have16 = false;
+    if (level == 2) level_up(S.id1, S.idx, 1);  // the pairs again (their memory held the 16-grams meanwhile)
+    // the lists of this level: every source whose gram lies inside the window, under its number
+    for (uint32_t i = tid; i < kGmSlots; i += kDmThreads) S.table[i] = kGmNone;
+    if (tid == 0) S.n_open[cur ^ 1] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < nsrc; i += kDmThreads) {
+      const uint32_t x = ids[i];
+      if (x < kGmUndefined) S.next[i] = (uint16_t)atomicExch(&S.table[x], i);
+    }
+    __syncthreads();
+    GM_PHASE_MARK(2);  // lists (and the pairs numbered again)
+    for (uint32_t j = tid; j < ((n_open + 63) & ~63u); j += kDmThreads) {
+      bool still_open = false;
+      uint32_t ip = 0;
+      if (j < n_open) {
+        ip = (cur ? S.todo1 : S.s.todo0)[j];
+        const uint32_t p = lo + ip, t = ip - ia;
+        const uint32_t rem = M - p < kMaxLen ? M - p : kMaxLen;
+        uint32_t key = S.s.keys[t];
+        const uint32_t x = ids[ip];
+        if (x < kGmUndefined) {
+          uint32_t q = S.table[x];
+          if (L == 1) {
+            uint32_t far = 0;
+            while (q != kGmNone) {
+              spent++;
+              if (q < ip && q + kWindow >= ip && ip - q > far) far = ip - q;
+              q = S.next[q];
+            }
+            const uint32_t k1 = far ? ((1u << 11) | far) : 0u;
+            key = k1 > key ? k1 : key;
+          } else {
+            while (q != kGmNone) {
+              spent++;
+              if (q < ip && q + kWindow >= ip) {
+                const uint32_t d = ip - q, cap = d < rem ? d : rem;
+                // what it must reach to replace the best so far: longer, or as long and farther (lz77.h:68)
+                const uint32_t need = (key >> 11) + (d > (key & 2047u) ? 0u : 1u);
+                if (cap >= need && (need <= 1 || S.id1[q + need - 1] == S.id1[ip + need - 1])) {
+                  const uint32_t l = lcp(q, ip, cap);
+                  if (l >= need) key = (l << 11) | d;
+                }
+              }
+              q = S.next[q];
+            }
+          }
+        }
+        if (L > 1 && (key >> 11) < L && p != M - 1) {
+          S.s.keys[t] = key;
+          still_open = true;
+        } else {
+          if (p == M - 1) key = 0;  // a lone look-ahead pixel is always a literal (lz77.h:42-49)
+          const uint32_t o = key ? ((key >> 11) | ((key & 2047u) << 8) | (dist_code_of(xsize, xinv, key & 2047u) << 19)) : 0u;
+          match[pos0 + p] = o;
+          adv[pos0 + p] = (uint8_t)((o & 0xff) ? (o & 0xff) : 1u);
+        }
+      }
+      // the positions that go on to the next level (whole waves get here)
+      const uint64_t m = __ballot(still_open);
+      if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&S.n_open[cur ^ 1], (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (still_open) (cur ? S.s.todo0 : S.todo1)[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)ip;
+      }
+      if (spent > kGmBudget) S.abort_flag = 1;
+    }
+    GM_PHASE_MARK(3 + level);  // search of the level (thread 0's share)
+    __syncthreads();
+    GM_PHASE_MARK(7 + level);  // waiting for the others
+    if (S.abort_flag) return false;  // too much to look at: the exhaustive kernel redoes the tile
+    cur ^= 1;
+    n_open = S.n_open[cur];
+    if (n_open == 0) break;
+  }
+  if (tid == 0) dense_tile[(pos0 + a) / kLzTile] = kTileDoneGrams;
+  return true;
 }
 
 // The tiles that k_lz77_sparse left to the exhaustive kernel.  Workgroups stay and take tiles from a counter, 16
@@ -579,20 +793,22 @@ __device__ __forceinline__ void lz77_dominant_tile(DmShared &S, const DmGeo &G, 
 // searched here gets the flag kTileDoneDominant; one that is not (no frequent value, too many run starts or list
 // entries) keeps its flag and is the exhaustive kernel's.  `counter` starts at 0 (cleared with the flags).
 constexpr uint32_t kDmChunk = 16;
-__global__ __launch_bounds__(kDmThreads, 4) void k_lz77_dominant(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
-                                                                 const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles,
-                                                                 const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
-                                                                 uint8_t *__restrict__ adv, uint8_t *__restrict__ dense_tile,
-                                                                 uint32_t *__restrict__ counter, uint32_t take_flag,
-                                                                 const uint32_t *__restrict__ waiting_tiles) {
-  __shared__ __attribute__((aligned(16))) DmShared S;
+// SEARCH(S, geo) searches one tile whose window is in S.px; the rest is the same for both kernels of this file.
+template <class Shared, class Search>
+__device__ __forceinline__ void dense_tiles(Shared &S, const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                            const uint32_t *__restrict__ sb_first, uint32_t n, uint32_t ntiles, const uint32_t *__restrict__ pix,
+                                            const uint8_t *__restrict__ dense_tile, uint32_t *__restrict__ counter, uint32_t take_flag,
+                                            const uint32_t *__restrict__ waiting_tiles, Search search) {
   __shared__ uint32_t s_chunk;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   // waiting_tiles (may be null): an upper bound of the tiles with the flag, counted by the kernel that set it.  None: nothing
   // to do (a look at a million flags of a batch that needs none of this took 0.76 ms); few: the flags are looked at 64 at a time
   const uint32_t n_waiting = waiting_tiles ? *waiting_tiles : ntiles;
   if (n_waiting == 0) return;
-  const uint32_t chunk_tiles = (uint64_t)n_waiting * 8 > ntiles ? kDmChunk : 64u;
+  // many waiting: few tile numbers at a time, so that the last workgroups do not work on alone (one tile at a time when there are
+  // hardly more tiles than workgroups); few waiting among many: 64 flags at a look
+  const uint32_t per_group = ntiles / (4 * gridDim.x);
+  const uint32_t chunk_tiles = (uint64_t)n_waiting * 8 > ntiles ? (per_group < 1 ? 1u : per_group > kDmChunk ? kDmChunk : per_group) : 64u;
   uint32_t chunk = 0;
   uint64_t waiting = 0;  // tiles of the chunk that are still to do (the same in every thread)
   // the next waiting tile, or ~0u when the counter has run past the last tile; called by all threads
@@ -630,12 +846,33 @@ __global__ __launch_bounds__(kDmThreads, 4) void k_lz77_dominant(const EncImage 
       if (i < geo.W) *reinterpret_cast<uint4 *>(&S.px[i]) = ahead[k];
     }
     const DmGeo cur = geo;
-    const uint32_t following = next_tile();  // (its barriers also make the window visible to everyone)
+    const uint32_t following = next_tile();
     if (following != ~0u) { geo = dm_geometry(imgs, st, sb_first, n, following); fetch_window(geo); }
-    if (cur.W) lz77_dominant_tile(S, cur, match, adv, dense_tile, take_flag == 0);
+    __syncthreads();  // the window is in place
+    if (cur.W) search(S, cur);
     __syncthreads();  // the tile's shared memory is the next tile's
     tile = following;
   }
+}
+
+__global__ __launch_bounds__(kDmThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_lz77_dominant(const EncImage *__restrict__ imgs, const EncState *__restrict__ st, const uint32_t *__restrict__ sb_first, uint32_t n,
+                     uint32_t ntiles, const uint32_t *__restrict__ pix, uint32_t *__restrict__ match, uint8_t *__restrict__ adv,
+                     uint8_t *__restrict__ dense_tile, uint32_t *__restrict__ counter, uint32_t take_flag,
+                     const uint32_t *__restrict__ waiting_tiles) {
+  __shared__ __attribute__((aligned(16))) DmShared S;
+  dense_tiles(S, imgs, st, sb_first, n, ntiles, pix, dense_tile, counter, take_flag, waiting_tiles,
+              [&](DmShared &sh, const DmGeo &g) { (void)lz77_dominant_tile(sh, g, match, adv, dense_tile, take_flag == 0); });
+}
+
+// What k_lz77_dominant left of the tiles that the candidate lists gave up on.
+__global__ __launch_bounds__(kDmThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_lz77_grams(const EncImage *__restrict__ imgs, const EncState *__restrict__ st, const uint32_t *__restrict__ sb_first, uint32_t n,
+                  uint32_t ntiles, const uint32_t *__restrict__ pix, uint32_t *__restrict__ match, uint8_t *__restrict__ adv,
+                  uint8_t *__restrict__ dense_tile, uint32_t *__restrict__ counter, const uint32_t *__restrict__ waiting_tiles) {
+  __shared__ __attribute__((aligned(16))) GmShared S;
+  dense_tiles(S, imgs, st, sb_first, n, ntiles, pix, dense_tile, counter, (uint32_t)kTileExhaustive, waiting_tiles,
+              [&](GmShared &sh, const DmGeo &g) { (void)lz77_grams_tile(sh, g, match, adv, dense_tile); });
 }
 
 }  // namespace vp8l
