@@ -167,11 +167,23 @@ def _timed_decode(dec, dargs, npx_total, reps):
     return reps * npx_total / 1e6 / dt, float(np.mean(dev_s)), st
 
 
-def _decode_roofline(bpp, npx_total, dev_s):
+def _decode_traffic(batch, w, h):
+    """HBM bytes of one decode call from the committed counter passes (profiles/decode_traffic.json), if they were made for this batch."""
+    path = os.path.join(ROOT, "profiles", "decode_traffic.json")
+    try:
+        tj = json.load(open(path))
+        if (tj.get("batch"), tj.get("width"), tj.get("height")) == (batch, w, h):
+            return tj.get("hbm_bytes_per_call")
+    except Exception:
+        pass
+    return None
+
+
+def _decode_roofline(bpp, npx_total, dev_s, traffic=None):
     alg = (bpp / 8.0 + 4.0) * npx_total   # stream bytes read + pixels written
     return {"kernel": "whole decode path (k_par_scout_lanes, k_par_place, k_par_jump, inverse transforms) over the end-to-end algorithmic bytes",
             "bound": "hbm", "achieved": alg / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dev_s / 1e9 / HBM_PEAK_GBS,
-            "traffic": None, "algorithmic_bytes_per_launch": alg}
+            "traffic": traffic, "algorithmic_bytes_per_launch": alg}
 
 
 def workload_decode1080p(args, world, rank, local_rank, dev):
@@ -208,7 +220,7 @@ def workload_decode1080p(args, world, rank, local_rank, dev):
                      "batch of %d synthetic %dx%d streams per rank (half photo-like, half graphics), VP8L decode "
                      "(BASELINE configs[3] = 4096 streams over 8 GPUs); streams and pixels resident in HBM" % (batch, w, h),
                      {"bits_per_pixel": bpp, "roundtrip_verified": ok, "device_ms_per_step": 1e3 * dev_s,
-                      "roofline": _decode_roofline(bpp, batch * npx, dev_s)})
+                      "roofline": _decode_roofline(bpp, batch * npx, dev_s, _decode_traffic(batch, w, h))})
     out["cpu_baseline"] = None
     if world == 1 and not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -423,7 +435,7 @@ OTHER_WORKLOADS = {"decode1080p": workload_decode1080p, "palette2k": workload_pa
 # what the default run adds to its line under "configs": BASELINE's other configurations, a few steps each
 CONFIG_RUNS = (("configs[0] single512", "single512"), ("configs[2] single16k", "single16k"), ("configs[3] decode1080p", "decode1080p"),
                ("configs[4] palette2k", "palette2k"), ("predictor4k", "predictor4k"))
-CONFIG_KEYS = ("metric", "value", "unit", "ms_per_step", "bits_per_pixel", "roundtrip_verified", "device_ms_per_step", "stage_ms_per_step",
+CONFIG_KEYS = ("metric", "value", "unit", "ms_per_step", "bits_per_pixel", "roundtrip_verified", "device_ms_per_step", "stage_ms_per_step", "roofline",
                "exhaustive_search_tiles", "tile_kinds", "encode_ms", "decode_ms", "device_resident", "reference_cpu_one_thread_ms", "cpu_baseline")
 
 
