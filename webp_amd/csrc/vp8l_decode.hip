@@ -1376,6 +1376,19 @@ constexpr uint32_t kLaneGuessRound = kLaneRounds * 3 / 4;             // the gue
 constexpr uint32_t kLaneRecCap = kParRecCap / kLanesPerSeg;           // token records per lane: tokens of 4 bits fill them
 static_assert(4 + kLanesPerSeg <= 64, "a segment's slots hold the lanes' record counts");
 static_assert(kLaneRecCap % 2 == 0, "records are stored in pairs");
+// What a store of several records at once relies on (a lane's part of the record array is its own; `tok` counts the lane's
+// records since the pass began):
+//   * the array starts at a multiple of 16 bytes (hipMalloc gives 256) and a segment's records, kParRecCap * 8 bytes, and a
+//     lane's part, kLaneRecCap * 8 bytes, are multiples of the store's width: the pair that ends at an odd `tok` starts at
+//     rec + tok - 1, a multiple of 16 bytes.  Groups of G records would need kLaneRecCap % G == 0 (true up to 2048) AND a flush
+//     of up to G - 1 held records on every way out of the pass (the end of the piece, a token that cannot be taken, the cap) -
+//     with pairs that is the one record `held`;
+//   * a record is held or stored only while tok < cap, and cap is even, so a held record always has room for its neighbour;
+//   * a pass that decodes a piece again rewrites the part from its first record; records behind the new count are stale and
+//     never read (the counts per part are what k_par_place goes by).
+// Wider groups were tried (four records, 32 bytes): 14 more registers, four waves per SIMD instead of five, and no gain
+// over pairs beyond the one the pairs already give; pairs are kept.
+static_assert((kParRecCap * 8) % 16 == 0 && (kLaneRecCap * 8) % 16 == 0, "every lane's part of the records starts at a multiple of 16 bytes");
 static_assert(kLaneBits < kParSegBits && (kLanesPerSeg & (kLanesPerSeg - 1)) == 0 && kLanesPerSeg <= 64, "the lanes of a segment sit in one wave");
 static_assert(kLaneThreads % 64 == 0 && kLaneThreads >= kNumCodes * kWgLongSlots, "whole waves; one thread per long-code slot");
 static_assert(64 % kLaneChunkWords == 0 && kLaneBits % kLaneChunkBits == 0 && kLaneBits % 64 == 0, "chunks");
@@ -2436,6 +2449,8 @@ int decode_pass(vp8l_decoder *d, const std::vector<uint32_t> &idx, const uint8_t
         !d->d_segidx.reserve((seg_total + m) * 2 * 4) || !d->d_segfirst.reserve((m + 1) * 4) || !d->d_lanefirst.reserve((m + 1) * 4) || !d->d_jumpflags.reserve(kParJumpPasses * 4) ||
         (whole_mode == 1 && !d->d_records.reserve(seg_total * kParRecCap * 8)))
       return VP8L_ERR_NO_MEMORY;
+    // the scouts store records 16 bytes at a time: the array must start at a multiple of 16 (see kLaneRecCap)
+    if (whole_mode == 1 && (reinterpret_cast<uintptr_t>(d->d_records.as<uint64_t>()) & 15u) != 0) return VP8L_ERR_HIP;
     for (uint32_t k = 0; k < m; k++) {
       pars[k].records = whole_mode == 1 ? d->d_records.as<uint64_t>() + reinterpret_cast<uintptr_t>(pars[k].records) : nullptr;
       pars[k].srcg = d->d_srcg.as<uint32_t>() + reinterpret_cast<uintptr_t>(pars[k].srcg);
