@@ -129,8 +129,10 @@ int vp8l_encode_device_noalloc(int device, void *stream, const uint32_t *d_argb,
 /* Options.  VP8L_OPT_MATCH_SEARCH: 0 (default) = candidate-list match search; tiles with heavy duplication go on to the
  * forms made for them (one frequent value; pairs of pixels) and last to the exhaustive search; 1 = exhaustive search
  * everywhere; 2 = the candidate lists refuse every tile, so the forms behind them see all of them; 3 = as 2, with one more
- * form (sources numbered by the 16, 4, 2 words that follow them) in front of the exhaustive search.  All give identical
- * streams; the option exists for verification and measurement. */
+ * form (sources numbered by the 16, 4, 2 words that follow them) in front of the exhaustive search; 4 = as 0, and the
+ * tiles of palette images that are left for the exhaustive search are searched only at the positions a parse can reach
+ * (the other positions of such a tile then read "no match" in the match array; no parse looks at them).  All give
+ * identical streams; the option exists for verification and measurement. */
 enum { VP8L_OPT_MATCH_SEARCH = 1, VP8L_OPT_PREDICTOR_BITS = 2, VP8L_OPT_CROSS_COLOR_BITS = 3, VP8L_OPT_STANDARD = 4,
        VP8L_OPT_CACHE_BITS = 5, VP8L_OPT_META_BITS = 6, VP8L_OPT_META_GROUPS = 7 };
 /* VP8L_OPT_PREDICTOR_BITS: 0 (default) = the reference encoder's output (subtract green or colour indexing only,

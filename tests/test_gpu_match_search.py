@@ -31,7 +31,7 @@ def run(img, w, h, exhaustive):
     return m, res, dense, total, data
 
 
-def check(img, w, h, expect=None, behind_the_lists=True):
+def check(img, w, h, expect=None, behind_the_lists=True, third_mode=3):
     """behind_the_lists: a third run in which the candidate lists refuse every tile, so that the forms behind them
     (frequent value, grams, then exhaustive) search all of it; its tile kinds are left in run.kinds."""
     m1, _, dense1, total1, s1 = run(img, w, h, 1)
@@ -41,14 +41,27 @@ def check(img, w, h, expect=None, behind_the_lists=True):
     ln, ds = O.lz77_best_all(res)
     results = [m0, m1]
     if behind_the_lists:
-        m2, _, _, _, s2 = run(img, w, h, 3)
+        m2, _, _, _, s2 = run(img, w, h, third_mode)
         assert s2 == s0
         results.append(m2)
     else:
         run.kinds = kinds0
-    for m in results:
-        assert np.array_equal(m & 0xFF, ln)
-        assert np.array_equal(np.where(ln > 0, (m >> 8) & 0x7FF, 0), ds)
+    # the search along the parse (palette images) leaves positions no parse can reach at "no match": every position is the
+    # oracle's or untouched, and every position a parse from one of a tile's first 128 positions gets to is the oracle's
+    on_a_chain = np.zeros(ln.size, dtype=bool)
+    adv = np.maximum(ln, 1).astype(np.int64)
+    for start in range(0, ln.size, 2048):
+        for e in range(start, min(start + (128 if start else 1), ln.size)):
+            p = e
+            while p < min(start + 2048, ln.size) and not on_a_chain[p]:
+                on_a_chain[p] = True
+                p += adv[p]
+    for k, m in enumerate(results):
+        same = ((m & 0xFF) == ln) & (np.where(ln > 0, (m >> 8) & 0x7FF, 0) == ds)
+        if k == 1:   # the exhaustive kernel alone
+            assert same.all()
+        assert (same | (m == 0)).all()
+        assert same[on_a_chain].all()
     assert s0 == s1
     rc, ref = O.encode(img, w, h)
     assert rc == 0 and s0 == ref
@@ -83,6 +96,27 @@ def test_two_colour_noise_needs_exhaustive():
     dense, total = check(img, 300, 40)
     assert run.kinds.get("lists", 0) <= 1, run.kinds  # (none of it is the candidate lists' in any mode)
     check(O.gen_image(5, 256, 64, 3, 2), 256, 64, None)
+
+
+@pytest.mark.parametrize("ncolors", [2, 4, 16])
+def test_bundled_palettes_are_searched_along_the_parse(ncolors):
+    w, h = 1024, 96
+    check(O.gen_image(5, w, h, 7, ncolors), w, h, third_mode=4)
+    assert run.kinds.get("parse_walk", 0) > 0, run.kinds
+
+
+def test_palette_walk_on_flat_periodic_and_noisy_bytes():
+    rng = np.random.default_rng(77)
+    pal = (np.arange(16, dtype=np.uint32) * np.uint32(0x00111111)) | np.uint32(0xFF000000)
+    w, h = 2048, 24
+    flat = np.full(w * h, pal[3], dtype=np.uint32)
+    flat[5000:5003] = pal[1]; flat[30000] = pal[2]
+    for img in (flat,
+                pal[np.tile(rng.integers(0, 16, size=37), w * h // 37 + 1)[: w * h]],        # period 37 pixels
+                pal[rng.integers(0, 2, size=w * h)],                                         # two colours, noise: 8 to a byte
+                pal[np.repeat(rng.integers(0, 4, size=w * h // 5 + 1), 5)[: w * h]],         # four colours in runs of five
+                pal[(rng.random(w * h) < 0.02).astype(np.int64) * rng.integers(1, 16, size=w * h)]):  # one colour with specks
+        check(img.astype(np.uint32), w, h, third_mode=4)
 
 
 def test_switch_inside_one_image():

@@ -9,9 +9,9 @@ TAG=${1:-prof}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-host --no-verify > $OUT/trace.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_lz77_sparse|k_parse_mark|k_bitcount|k_emit" --output-format csv -d $OUT/fetch -o fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-host --no-verify > $OUT/fetch.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_lz77_sparse|k_parse_mark|k_bitcount|k_emit" --output-format csv -d $OUT/write -o write -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-host --no-verify > $OUT/write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-host --no-verify --no-configs > $OUT/trace.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_lz77_sparse|k_parse_mark|k_bitcount|k_emit" --output-format csv -d $OUT/fetch -o fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-host --no-verify --no-configs > $OUT/fetch.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_lz77_sparse|k_parse_mark|k_bitcount|k_emit" --output-format csv -d $OUT/write -o write -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-host --no-verify --no-configs > $OUT/write.log 2>&1
 for W in decode1080p palette2k single16k predictor4k; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -o trace -- python3 bench.py --workload $W --steps 3 --warmup 1 --no-cpu --no-host > $OUT/trace_$W.log 2>&1
 done

@@ -324,7 +324,8 @@ class Encoder:
 
     def set_match_search(self, mode):
         """0 (default): candidate lists first; 1: exhaustive everywhere; 2: the candidate lists refuse every tile; 3: as 2, with the
-        search by numbered grams in front of the exhaustive one (same matches every way)."""
+        search by numbered grams in front of the exhaustive one; 4: as 0, with the search along the parse for palette images' dense
+        tiles (same streams every way)."""
         rc = lib().vp8l_encoder_set_option(self._h, 1, int(mode))
         if rc != OK:
             raise Vp8lError(rc, "vp8l_encoder_set_option")
@@ -374,7 +375,7 @@ class Encoder:
         total = lib().vp8l_encoder_last_tile_kinds(self._h, buf)
         if total < 0:
             raise Vp8lError(int(total), "vp8l_encoder_last_tile_kinds")
-        names = {0: "lists", 1: "exhaustive", 2: "pairs", 4: "frequent_value", 5: "grams"}
+        names = {0: "lists", 1: "exhaustive", 2: "pairs", 4: "frequent_value", 5: "grams", 6: "parse_walk"}
         return {names.get(k, "flag%d" % k): int(buf[k]) for k in range(8) if buf[k]}
 
     def last_stage_seconds(self):

@@ -37,7 +37,7 @@ struct BitSink {
 
 template <int N>
 struct HuffScratchT {  // for alphabets of up to N symbols
-  uint32_t wt[2 * N];
+  uint32_t wt[2 * N];   // (also the work area of canonical_reversed_codes once the lengths are known)
   uint16_t parent[2 * N];
   uint16_t ord[N];
   uint16_t stack[N];
@@ -149,8 +149,13 @@ VP8L_HD int huffman_lengths_limited(uint32_t *histo, int n, int limit, uint8_t *
 
 // Canonical codes in symbol order (huffman_coding.cpp:8-49), bit-reversed for the LSB-first
 // writer (huffman_coding.h:356-363,415-418).  Lengths <= 32.
-VP8L_HD void canonical_reversed_codes(const uint8_t *lengths, int n, uint32_t *codes) {
-  uint32_t count[kSaneCodeLen + 2], next[kSaneCodeLen + 2];
+// work: kCanonWork words for the two small tables (symbols per length, next code per length).  On the GPU a caller passes
+// shared memory: arrays of a function that are indexed by a variable live in a lane's private memory there, and the two
+// loops over the symbols are chains of read-modify-writes of it, each several hundred cycles.  Null: local arrays.
+constexpr int kCanonWork = 2 * (kSaneCodeLen + 2);
+VP8L_HD void canonical_reversed_codes(const uint8_t *lengths, int n, uint32_t *codes, uint32_t *work = nullptr) {
+  uint32_t local[kCanonWork];
+  uint32_t *count = work ? work : local, *next = count + kSaneCodeLen + 2;
   for (int l = 0; l <= kSaneCodeLen + 1; l++) count[l] = 0;
   int maxl = 0;
   for (int i = 0; i < n; i++) { count[lengths[i]]++; if (lengths[i] > maxl) maxl = lengths[i]; }
@@ -224,7 +229,7 @@ VP8L_HD int write_code_desc(BitSink &bw, const uint8_t *lengths, int n, Desc &s,
   const int used = standard ? huffman_lengths_limited(s.cl_histo, dl.ncl, dl.max_cl_len, s.cl_len, s.huff)
                             : huffman_lengths(s.cl_histo, dl.ncl, dl.max_cl_len, s.cl_len, s.huff);
   if (used < 0) return used;
-  canonical_reversed_codes(s.cl_len, dl.ncl, s.cl_code);
+  canonical_reversed_codes(s.cl_len, dl.ncl, s.cl_code, s.huff.wt);  // (the code is built: its scratch is free)
   int nwrite = dl.ncl;
   while (nwrite > 4 && s.cl_len[dl.order(nwrite - 1)] == 0) nwrite--;
   bw.put((uint32_t)(nwrite - 4), (uint32_t)dl.count_bits);
@@ -262,7 +267,7 @@ VP8L_HD int build_and_write_codes(BitSink &bw, uint32_t *histo /*[5*kCodeStride]
                               : huffman_lengths(histo + c * kCodeStride, n, kMaxCodeLen, len, s.huff);
     if (used < 0) return used;
     t.used[c] = (uint32_t)used;
-    canonical_reversed_codes(len, n, t.code + c * kCodeStride);
+    canonical_reversed_codes(len, n, t.code + c * kCodeStride, s.huff.wt);
     const int rc = write_code_desc(bw, len, n, s, standard);
     if (rc < 0) return rc;
   }

@@ -707,6 +707,14 @@ static_assert(kSpTile / kSpThreads == 4, "positions of a thread are handled as t
 // `grouped` below): with that path compiled in, the common path of this kernel got 12 % slower (60 instead of 40
 // registers, other schedules), and those tiles are few or many by the kind of image, so they are listed and redone.
 constexpr uint8_t kTileExhaustive = 1, kTilePairs = 2;
+// Leaves a tile to the exhaustive search: its flag, the count of such tiles, and - for the first kFewTiles of a call - its
+// number in the list behind the counters (given_up points at the count; the list begins kFewListAt words behind it).
+constexpr uint32_t kFewListAt = 14;
+__device__ __forceinline__ void give_up_tile(uint8_t *__restrict__ dense_tile, uint32_t *__restrict__ given_up, uint32_t tile) {
+  dense_tile[tile] = kTileExhaustive;
+  const uint32_t k = atomicAdd(given_up, 1u);
+  if (k < kFewTiles) given_up[kFewListAt + k] = tile;
+}
 constexpr uint8_t kTileDoneDominant = 4;  // searched by k_lz77_dominant (vp8l_encode_dense.h), before or after this kernel
 template <bool PAIRS_KERNEL>
 __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
@@ -729,7 +737,7 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
   __shared__ uint32_t items[kSpSources];   // (low bits of the mixed pixel) << 11 | index in px
   __shared__ uint32_t wsum[kSpWaves];
   __shared__ uint32_t wmin[kSpWaves];
-  __shared__ uint32_t s_abort, s_inside, s_sumsq, s_heavy;
+  __shared__ uint32_t s_abort, s_inside, s_sumsq, s_heavy, s_given;
   constexpr uint32_t kPerSuper = kSuper / kSpTile;
   const uint32_t tid = threadIdx.x;
   const uint32_t sb = tile / kPerSuper, img = find_image(sb_first, n, sb);
@@ -748,7 +756,7 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
   const uint32_t lane = tid & 63, wave = tid >> 6;
   VP8L_PHASE_BEGIN();
   for (uint32_t i = tid; i < kSpBuckets / 2; i += kSpThreads) cursor2[i] = 0;
-  if (tid == 0) { s_abort = 0; s_inside = 0; s_sumsq = 0; s_heavy = 0; }
+  if (tid == 0) { s_abort = 0; s_inside = 0; s_sumsq = 0; s_heavy = 0; s_given = 0; }
   // lo is a multiple of 4 (a and kWindow are) and the pixel array has readable slack past M: 16-byte loads
   if (!PAIRS_KERNEL && st[img].fused) {
     // Subtract-green path: the residual is made here from the caller's pixels (vp8l.h:594-597,
@@ -851,7 +859,7 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
   if (mx > tune_max_bucket) s_abort = 1;
   if (mx >= kSpHeavyBucket) s_heavy = 1;
   __syncthreads();
-  if (s_abort) { if (tid == 0) { dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; atomicAdd(given_up, 1u); } return; }
+  if (s_abort) { if (tid == 0) { give_up_tile(dense_tile, given_up, (uint32_t)((pos0 + a) / kLzTile)); } return; }
   uint32_t run = incl - sum;
   for (uint32_t k = 0; k < wave; k++) run += wsum[k];
   uint32_t entries = 0;  // of all buckets (counted for tiles with a full bucket only)
@@ -869,7 +877,7 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
     if (lane == 0 && sq) atomicAdd(&s_sumsq, sq);
     __syncthreads();
     for (uint32_t k = 0; k < kSpWaves; k++) entries += wsum[k];
-    if (s_sumsq > tune_mean_bucket * entries) { if (tid == 0) { dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; atomicAdd(given_up, 1u); } return; }
+    if (s_sumsq > tune_mean_bucket * entries) { if (tid == 0) { give_up_tile(dense_tile, given_up, (uint32_t)((pos0 + a) / kLzTile)); } return; }
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -1104,7 +1112,7 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
         else { open_positions[2] = still_open[0]; open_positions[3] = still_open[1]; }
       }
       if (__ballot(spent > tune_budget)) {  // too much work for this form: the exhaustive kernel redoes the tile
-        if (lane == 0) { dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; atomicAdd(given_up, 1u); }
+        if (lane == 0 && atomicExch(&s_given, 1u) == 0) give_up_tile(dense_tile, given_up, (uint32_t)((pos0 + a) / kLzTile));  // (once per tile: every wave gets here on its own)
         return true;
       }
     }
@@ -1242,7 +1250,7 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
   if (over) s_abort = 1;
   __syncthreads();
   VP8L_PHASE_MARK(5);  // waiting for the other waves
-  if (s_abort) { if (tid == 0) { dense_tile[(pos0 + a) / kLzTile] = kTileExhaustive; atomicAdd(given_up, 1u); } return; }
+  if (s_abort) { if (tid == 0) { give_up_tile(dense_tile, given_up, (uint32_t)((pos0 + a) / kLzTile)); } return; }
 #pragma unroll
   for (uint32_t k = 0; k < kSpTile / kSpThreads; k++) {
     const uint32_t p = a + k * kSpThreads + tid;
@@ -1291,13 +1299,17 @@ __global__ __launch_bounds__(kSpThreads, 8) void k_lz77_pairs(const EncImage *__
 
 }  // namespace vp8l
 #include "vp8l_encode_dense.h"
+#include "vp8l_encode_walk.h"
 namespace vp8l {
 
 __global__ __launch_bounds__(256, 4) void k_lz77(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                               const uint32_t *__restrict__ sb_first, uint32_t n,
                                               const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
-                                              uint8_t *__restrict__ adv, const uint8_t *__restrict__ dense_tile) {
+                                              uint8_t *__restrict__ adv, const uint8_t *__restrict__ dense_tile,
+                                              const uint32_t *__restrict__ given_up) {
   constexpr uint32_t kPerSuper = kSuper / kLzBlock;
+  // none given up on: nothing to do; few: k_lz77_pieces searches them
+  if (given_up && (uint32_t)__builtin_amdgcn_readfirstlane((int)*given_up) <= kFewTiles) return;
   // tiles the candidate-list kernel completed are done; it flags the ones it gave up on (tile number = wave number)
   if (dense_tile && __builtin_amdgcn_readfirstlane((int)dense_tile[blockIdx.x * kLzWaves + (threadIdx.x >> 6)]) != kTileExhaustive) return;
   const uint32_t blk = blockIdx.x, sb = blk / kPerSuper, img = find_image(sb_first, n, sb);
@@ -1311,6 +1323,35 @@ __global__ __launch_bounds__(256, 4) void k_lz77(const EncImage *__restrict__ im
   const uint64_t pos0 = imgs[img].pos0;
   const uint32_t xsize = st[img].xsize, xinv = st[img].xinv;
   lz77_tile<false>(pix + pos0, match + pos0, adv + pos0, M, a, b, lane, xsize, xinv);
+}
+
+// The same when a call leaves few tiles to this search (one small image, a few odd tiles of a batch): a wave per tile would
+// leave most of the device idle for the 0.3 ms a tile takes, so each tile is cut into pieces of kLzPiece positions, a wave
+// each (a piece first warms up on the 143 positions behind it: half as much work again, done by eight times the waves).
+// Workgroup k takes the k-th tile of the list that give_up_tile keeps.
+constexpr uint32_t kLzPiece = 256;
+__global__ __launch_bounds__(64 * (kLzTile / kLzPiece)) void k_lz77_pieces(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                                          const uint32_t *__restrict__ sb_first, uint32_t n,
+                                                                          const uint32_t *__restrict__ pix, uint32_t *__restrict__ match,
+                                                                          uint8_t *__restrict__ adv, const uint8_t *__restrict__ dense_tile,
+                                                                          const uint32_t *__restrict__ given_up) {
+  const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)*given_up);
+  if (count > kFewTiles || blockIdx.x >= count) return;
+  const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)given_up[kFewListAt + blockIdx.x]);
+  if (dense_tile[tile] != kTileExhaustive) return;  // (another form has searched it since)
+  constexpr uint32_t kPerSuper = kSuper / kLzTile;
+  const uint32_t img = find_image(sb_first, n, tile / kPerSuper);
+  const uint32_t M = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[img].M);
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t t0 = (tile - sb_first[img] * kPerSuper) * kLzTile;
+  uint32_t a = t0 + wave * kLzPiece;
+  uint32_t b = a + kLzPiece;
+  b = b < M ? b : M;
+  if (a < kLzHead) a = kLzHead;  // the first positions of an image are k_lz77_head's
+  if (a >= b) return;
+  const uint64_t pos0 = imgs[img].pos0;
+  lz77_tile<false>(pix + pos0, match + pos0, adv + pos0, M, a, b, lane, st[img].xsize, st[img].xinv);
 }
 
 // The first kLzHead positions of every image: there, distances reach before the first pixel.  A kernel of its own,
@@ -1622,7 +1663,7 @@ __device__ __forceinline__ void build_codes_4waves(uint32_t *histo5, CodeTables 
       rc[c] = u;
       if (u >= 0) {
         t.used[c] = (uint32_t)u;
-        canonical_reversed_codes(len, nsym, t.code + c * kCodeStride);
+        canonical_reversed_codes(len, nsym, t.code + c * kCodeStride, hs.wt);
       }
       if (dbuf) {
         BitSink b;
@@ -2142,7 +2183,7 @@ struct vp8l_encoder {
   // workspace (grown on demand)
   DeviceBuffer d_imgs, d_state, d_sbfirst, d_gsets, d_pix, d_match, d_flags, d_histo, d_tables, d_sx, d_entry,
       d_unit_bits, d_unit_off, d_dense, d_group_bits, d_adv, d_pix2, d_modes, d_elems;
-  int match_mode = 0;  // 0 = candidate lists with the other forms behind them, 1 = exhaustive only, 2 = the candidate lists give up on every tile
+  int match_mode = 0;  // 0 = candidate lists with the other forms behind them, 1 = exhaustive only, 2 = the candidate lists give up on every tile, 3 = 2 + grams, 4 = 0 + search along the parse
                        // (verification of what comes behind them), 3 = the same with k_lz77_grams between k_lz77_dominant and the exhaustive kernel
   const uint32_t *last_pix = nullptr;  // coded pixels of the last call (for fetch_stage)
   bool last_pred = false;
@@ -2197,14 +2238,15 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
                                  int match_mode, uint8_t *d_out, hipEvent_t *ev, uint32_t standard = 0, const ExtArgs *extp = nullptr,
                                  uint32_t meta_bits = 0) {
   // match_mode 2: the candidate lists refuse every tile (no bucket may hold anything), so that the forms behind them see all tiles
-  const uint32_t tune_max_bucket = match_mode >= 2 ? 0u : g_tune[2];
+  const uint32_t tune_max_bucket = (match_mode == 2 || match_mode == 3) ? 0u : g_tune[2];
   const bool with_grams = match_mode == 3 || (g_tune[3] & 2u);
+  const bool with_walk = match_mode == 4 || (g_tune[3] & 4u);  // match_mode 4: as 0, with the search along the parse for palette images
   if (match_mode >= 2) match_mode = 0;
   bool h = true;
   h = h && hip_ok(hipMemsetAsync(B.st, 0, nl * sizeof(EncState), s), "clear state");
   h = h && hip_ok(hipMemsetAsync(B.gsets, 0xff, (size_t)nl * kSetSlots * sizeof(unsigned long long), s), "clear sets");
   h = h && hip_ok(hipMemsetAsync(B.histo, 0, (size_t)nl * kNumCodes * kCodeStride * 4, s), "clear histograms");
-  h = h && hip_ok(hipMemsetAsync(B.dense, 0, (size_t)sb_total * (kSuper / kLzTile) + kDenseTail, s), "clear tile flags");  // and the work counter behind them
+  h = h && hip_ok(hipMemsetAsync(B.dense, 0, (size_t)sb_total * (kSuper / kLzTile) + 16 + kDenseTail, s), "clear tile flags");  // and the work counter behind them
   if (!h) return VP8L_ERR_HIP;
   auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], s); };
   const uint32_t gsb = sb_total, gunits = sb_total * kUnitsPerSuper;
@@ -2246,10 +2288,22 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
     if (with_grams)
       hipLaunchKernelGGL(k_lz77_grams, dim3(dm_grid), dim3(kDmThreads), 0, s, B.imgs, B.st, B.sbf, nl, gsb * (kSuper / kSpTile), B.pix, B.match,
                          B.adv8, B.dense, dm_counter + 3, (const uint32_t *)(dm_counter + 2));
+    // ... and of palette images, what is still waiting, only where a parse can get to: exact; a fifth faster than the exhaustive kernel
+    // on 16-colour images (two pixels to a byte), several times slower where a tile begins inside a flat or periodic stretch (the
+    // chains from its 128 possible entries then never join), so only on request as well
+    if (with_walk)
+      hipLaunchKernelGGL(k_lz77_walk, dim3(std::min<uint32_t>(gsb * (kSuper / kSpTile), kWkGrid)), dim3(kWkThreads), 0, s, B.imgs, B.st, B.sbf, nl,
+                         gsb * (kSuper / kSpTile), B.pix, B.match, B.adv8, B.dense, dm_counter + 4, (const uint32_t *)(dm_counter + 2));
   }
   mark(9);  // also when the candidate-list kernel is switched off
-  hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,
-                     match_mode == 0 ? B.dense : (const uint8_t *)nullptr);
+  {
+    const uint32_t *given_up = match_mode == 0 ? reinterpret_cast<const uint32_t *>(B.dense + (((size_t)sb_total * (kSuper / kLzTile) + 15) & ~(size_t)15)) + 2 : nullptr;
+    hipLaunchKernelGGL(k_lz77, dim3(gsb * (kSuper / kLzBlock)), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,
+                       match_mode == 0 ? B.dense : (const uint8_t *)nullptr, given_up);
+    if (given_up)
+      hipLaunchKernelGGL(k_lz77_pieces, dim3(kFewTiles), dim3(64 * (kLzTile / kLzPiece)), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,
+                         (const uint8_t *)B.dense, given_up);
+  }
   hipLaunchKernelGGL(k_lz77_head, dim3(nl * (kLzHead / kLzHeadPiece)), dim3(64), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.adv8,
                      match_mode == 0 ? B.dense : (const uint8_t *)nullptr);
   mark(3);
@@ -2390,7 +2444,7 @@ static int vp8l_encoder_encode_device_impl(vp8l_encoder *e, size_t n, const uint
             e->d_histo.reserve((size_t)nl * kNumCodes * kCodeStride * 4) && e->d_tables.reserve((size_t)nl * sizeof(CodeTables)) &&
             e->d_sx.reserve(sb_total * kBlockLen) && e->d_entry.reserve(sb_total) &&
             e->d_unit_bits.reserve(nunits * 4) && e->d_unit_off.reserve(nunits * 8) &&
-            e->d_dense.reserve(sb_total * (kSuper / kLzTile) + kDenseTail) && e->d_group_bits.reserve(npos / 16 * 2) && e->d_adv.reserve(npos) &&
+            e->d_dense.reserve(sb_total * (kSuper / kLzTile) + 16 + kDenseTail) && e->d_group_bits.reserve(npos / 16 * 2) && e->d_adv.reserve(npos) &&
             ((e->pred_bits == 0 && e->cross_bits == 0) ||
              (e->d_pix2.reserve(npos * 4) && e->d_modes.reserve((size_t)nl * kSmallMax * 4) && e->d_elems.reserve((size_t)nl * kSmallMax * 4)));
   if (!ok) return VP8L_ERR_NO_MEMORY;
@@ -2557,7 +2611,7 @@ extern "C" double vp8l_encoder_last_device_seconds(const vp8l_encoder *e) { retu
 extern "C" int vp8l_encoder_set_option(vp8l_encoder *e, int option, int value) {
   if (!e) return VP8L_ERR_BAD_ARGUMENT;
   std::lock_guard<std::mutex> lock(e->mu);
-  if (option == VP8L_OPT_MATCH_SEARCH && value >= 0 && value <= 3) { e->match_mode = value; return VP8L_OK; }
+  if (option == VP8L_OPT_MATCH_SEARCH && value >= 0 && value <= 4) { e->match_mode = value; return VP8L_OK; }
   if (option == VP8L_OPT_PREDICTOR_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->pred_bits = value; return VP8L_OK; }
   if (option == VP8L_OPT_CROSS_COLOR_BITS && (value == 0 || (value >= 2 && value <= 9))) { e->cross_bits = value; return VP8L_OK; }
   if (option == VP8L_OPT_STANDARD && (value == 0 || value == 1)) { e->standard = value != 0; return VP8L_OK; }
@@ -2653,7 +2707,7 @@ constexpr uint64_t kNaEntry = kNaSx + na_align(kNaSuper * kBlockLen);
 constexpr uint64_t kNaUbits = kNaEntry + na_align(kNaSuper);
 constexpr uint64_t kNaUoff = kNaUbits + na_align(kNaSuper * kUnitsPerSuper * 4);
 constexpr uint64_t kNaDense = kNaUoff + na_align(kNaSuper * kUnitsPerSuper * 8);
-constexpr uint64_t kNaGbits = kNaDense + na_align(kNaSuper * (kSuper / kLzTile) + kDenseTail);
+constexpr uint64_t kNaGbits = kNaDense + na_align(kNaSuper * (kSuper / kLzTile) + 16 + kDenseTail);  // (the counters behind the flags start at a multiple of 16)
 constexpr uint64_t kNaFlags = kNaGbits + na_align(kNaPos / 16 * 2);
 constexpr uint64_t kNaAdv = kNaFlags + na_align(kNaPos / 8);
 constexpr uint64_t kNaPix = kNaAdv + na_align(kNaPos);

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void k_ext_codes(const EncState *__restrict__ s
     int u = x.standard ? huffman_lengths_limited(h, nsym, dl.max_len, sh.len, sh.huff, used0) : huffman_lengths(h, nsym, dl.max_len, sh.len, sh.huff, used0);
     int rc = u < 0 ? u : 0;
     if (u >= 0) {
-      canonical_reversed_codes(sh.len, nsym, codes);
+      canonical_reversed_codes(sh.len, nsym, codes, sh.huff.wt);
       bw.init(x.desc + (grp * kNumCodes + c) * kExtDescWords);
       rc = write_code_desc(bw, sh.len, nsym, sh.desc, x.standard != 0);
       bw.flush();

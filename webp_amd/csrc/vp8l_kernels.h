@@ -22,7 +22,8 @@ constexpr uint32_t kLzBlock = kLzTile * kLzWaves;
 constexpr uint32_t kLzHead = 1024;      // positions at the start of an image that have fewer than 1024 distances (= the window)
 constexpr uint32_t kLzHeadPiece = 128;  // ... searched in pieces of this many
 constexpr uint32_t kTailPad = 64;       // readable slack behind every image's region
-constexpr uint32_t kDenseTail = 64;     // bytes behind the per-tile flags of the match search: a work counter, cleared with them
+constexpr uint32_t kFewTiles = 512;    // a call that leaves at most this many tiles to the exhaustive search has them searched in pieces
+constexpr uint32_t kDenseTail = 64 + kFewTiles * 4;  // bytes behind the per-tile flags of the match search, cleared with them: work counters, then the numbers of the first kFewTiles tiles given up on
 
 struct EncImage {          // host-written
   const uint32_t *argb;
