@@ -68,25 +68,10 @@ VP8L_HD uint32_t bit_reverse(uint32_t v, int len) {
 // Returns the number of used symbols, or -3 (TooBigCodeLength, huffman_coding.h:410-413).
 // n <= kCodeStride.  presorted_used >= 0: the caller has already filled s.wt[0..used) with the used
 // symbols' weights in symbol order and s.ord with the leaf ids sorted by (weight, id).
+// The joins alone: s.wt[0..used) and s.ord as above; fills s.parent and returns the number of nodes (the root is the last).
 template <class Scratch>
-VP8L_HD int huffman_lengths(const uint32_t *histo, int n, int max_len, uint8_t *lengths, Scratch &s, int presorted_used = -1) {
-  int nn = 0;
-  if (presorted_used < 0) {
-    for (int i = 0; i < n; i++)
-      if (histo[i]) s.wt[nn++] = histo[i];
-    // leaf k is the k-th used symbol; stable insertion sort of leaf ids by weight
-    for (int i = 0; i < nn; i++) {
-      int j = i;
-      const uint32_t w = s.wt[i];
-      while (j > 0 && s.wt[s.ord[j - 1]] > w) { s.ord[j] = s.ord[j - 1]; j--; }
-      s.ord[j] = (uint16_t)i;
-    }
-  } else {
-    nn = presorted_used;
-  }
-  const int used = nn;
-  for (int i = 0; i < n; i++) lengths[i] = 0;
-  if (used == 0) return 0;
+VP8L_HD int huffman_join(Scratch &s, int used) {
+  int nn = used;
   int lp = 0;          // next leaf in ord
   int top = 0;         // stack height (s.stack)
   int pend = used;     // internal nodes pend..nn-1 are not on the stack yet
@@ -108,6 +93,29 @@ VP8L_HD int huffman_lengths(const uint32_t *histo, int n, int max_len, uint8_t *
     if (top > 0 && pend == nn && w == run_w) { s.stack[top++] = (uint16_t)nn; pend = nn + 1; }  // joins the run on the stack, newest
     nn++;
   }
+  return nn;
+}
+
+template <class Scratch>
+VP8L_HD int huffman_lengths(const uint32_t *histo, int n, int max_len, uint8_t *lengths, Scratch &s, int presorted_used = -1) {
+  int nn = 0;
+  if (presorted_used < 0) {
+    for (int i = 0; i < n; i++)
+      if (histo[i]) s.wt[nn++] = histo[i];
+    // leaf k is the k-th used symbol; stable insertion sort of leaf ids by weight
+    for (int i = 0; i < nn; i++) {
+      int j = i;
+      const uint32_t w = s.wt[i];
+      while (j > 0 && s.wt[s.ord[j - 1]] > w) { s.ord[j] = s.ord[j - 1]; j--; }
+      s.ord[j] = (uint16_t)i;
+    }
+  } else {
+    nn = presorted_used;
+  }
+  const int used = nn;
+  for (int i = 0; i < n; i++) lengths[i] = 0;
+  if (used == 0) return 0;
+  nn = huffman_join(s, used);
   // depths from the root down (a parent is always created after its children)
   s.depth[nn - 1] = 0;
   for (int v = nn - 2; v >= 0; v--) s.depth[v] = (uint16_t)(s.depth[s.parent[v]] + 1);
@@ -279,7 +287,7 @@ VP8L_HD int build_and_write_codes(BitSink &bw, uint32_t *histo /*[5*kCodeStride]
 // farthest candidate wins ties, the final element is always a literal.  adv[p] = match length at
 // p (0 = literal), dst[p] = its distance.  O(n^2): next_mis[d] tracks, while p runs backwards,
 // the first position q >= p with data[q-d] != data[q].
-struct SmallLzScratch {
+struct alignas(4) SmallLzScratch {
   uint16_t next_mis[kSmallMax + 1];
   uint16_t len[kSmallMax];
   uint16_t dist[kSmallMax];

@@ -1611,11 +1611,14 @@ struct HeaderShared {
   uint32_t palette[kMaxPalette];
   DescScratch desc[3];     // waves 1..3; wave 0 uses sub.desc
   int rc[kNumCodes];
-  // the five descriptions of the main image's codes, written side by side and then appended to the stream
-  uint32_t dbuf[kNumCodes][kDescBufWords];
+  // the five descriptions of the main image's codes, written side by side and then appended to the stream: dbits[c] bits each,
+  // in five buffers of kDescBufWords words that lie where the sub-images' match search had its arrays (sub.lz; the
+  // sub-images are written by then) - with buffers of their own only two workgroups fit a CU instead of three
   uint32_t dbits[kNumCodes];
   int drc[kNumCodes];
 };
+static_assert(sizeof(SmallLzScratch) >= sizeof(uint32_t) * kNumCodes * kDescBufWords && alignof(SmallLzScratch) >= 4, "the descriptions fit where the sub-image search was");
+static_assert(sizeof(HeaderShared) + 64 <= 160 * 1024 / 3, "three workgroups of k_entropy_header per CU");
 
 // The used symbols' weights in symbol order and their ids sorted by (weight, id), by the whole wave
 // (what huffman_lengths otherwise does with a serial insertion sort).  Returns the number of used symbols.
@@ -1643,9 +1646,102 @@ __device__ __forceinline__ int wave_prepare_leaves(const uint32_t *h, int n, Scr
   return (int)count;
 }
 
+// huffman_lengths (vp8l_enc_core.h) by a whole wave, after wave_prepare_leaves: the joins are one lane's (each needs the one
+// before), the rest is not - the depth of every node by pointer jumping (a node's entry is parent << 16 | steps to it; eight
+// rounds of "add my parent's steps, take its parent" reach 256 levels, and anything deeper than the longest code allowed
+// fails either way), the lengths of the symbols from the depths of their leaves, the longest by a wave maximum.  One lane
+// going through the same loops took 0.1 ms of dependent shared-memory reads per code.  Returns the same in every lane.
+template <class Scratch>
+__device__ __forceinline__ int wave_huffman_lengths(const uint32_t *h, int n, int max_len, uint8_t *lengths, Scratch &hs, int used, uint32_t lane) {
+  constexpr int kPerLane = (2 * kCodeStride + 63) / 64;
+  int nn = used;
+  if (lane == 0 && used > 1) nn = huffman_join(hs, used);
+  nn = __builtin_amdgcn_readfirstlane(nn);
+  __builtin_amdgcn_wave_barrier();
+  uint32_t *x = hs.wt;  // (the weights are not needed any more)
+  for (int v = (int)lane; v < nn; v += 64) x[v] = v == nn - 1 ? ((uint32_t)v << 16) : (((uint32_t)hs.parent[v] << 16) | 1u);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+  for (int round = 0; round < 8; round++) {
+    uint32_t next[kPerLane];
+#pragma unroll
+    for (int k = 0; k < kPerLane; k++) {
+      const int v = k * 64 + (int)lane;
+      next[k] = 0;
+      if (v < nn) {
+        const uint32_t mine = x[v], up = x[mine >> 16];
+        next[k] = (up & 0xffff0000u) | ((mine & 0xffffu) + (up & 0xffffu));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // (a wave's shared-memory accesses keep their order: every read above comes before the writes below)
+#pragma unroll
+    for (int k = 0; k < kPerLane; k++) {
+      const int v = k * 64 + (int)lane;
+      if (v < nn) x[v] = next[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  uint32_t leaf0 = 0, maxl = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + (int)lane;
+    const uint32_t w = i < n ? h[i] : 0u;
+    const uint64_t mask = __ballot(w != 0);
+    if (i < n) {
+      uint32_t d = 0;
+      if (w) {
+        d = x[leaf0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] & 0xffffu;
+        if (used == 1) d = 1;  // a lone symbol gets length 1 (huffman_coding.h:398-402)
+      }
+      lengths[i] = (uint8_t)(d > 255 ? 255 : d);
+      maxl = d > maxl ? d : maxl;
+    }
+    leaf0 += (uint32_t)__popcll(mask);
+  }
+  __builtin_amdgcn_wave_barrier();
+  maxl = wave_max_dpp(maxl);
+  if ((int)maxl > max_len || (int)maxl > kSaneCodeLen) return -3;
+  return used;
+}
+
+// canonical_reversed_codes (vp8l_enc_core.h) by a whole wave: symbols per length by shared-memory atomics, the first code of
+// every length by one lane (32 steps), then 64 symbols at a time in symbol order - a symbol's code is the next free one of
+// its length plus the number of lanes before it with the same length.  work: kCanonWork words of shared memory.
+__device__ __forceinline__ void wave_canonical_codes(const uint8_t *lengths, int n, uint32_t *codes, uint32_t *work, uint32_t lane) {
+  uint32_t *count = work, *next = work + kSaneCodeLen + 2;
+  if (lane < (uint32_t)kSaneCodeLen + 2) count[lane] = 0;
+  __builtin_amdgcn_wave_barrier();
+  for (int i = (int)lane; i < n; i += 64) { const uint32_t l = lengths[i]; if (l) atomicAdd(&count[l], 1u); }
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    uint32_t cur = 0;
+    next[0] = 0;
+    for (int l = 1; l <= kSaneCodeLen; l++) { cur = (cur + count[l - 1]) << 1; next[l] = cur; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + (int)lane;
+    const uint32_t l = i < n ? lengths[i] : 0u;
+    uint32_t code = 0;
+    uint64_t todo = __ballot(l != 0);
+    while (todo) {
+      const uint32_t first = (uint32_t)__builtin_ctzll(todo);
+      const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)l, (int)first);
+      const uint64_t same = __ballot(l == l0);
+      const uint32_t free0 = next[l0];
+      if (l == l0) code = free0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+      __builtin_amdgcn_wave_barrier();
+      if (lane == first) next[l0] = free0 + (uint32_t)__popcll(same);
+      __builtin_amdgcn_wave_barrier();
+      todo &= ~same;
+    }
+    if (i < n) codes[i] = l ? (__builtin_bitreverse32(code) >> (32u - l)) : 0u;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // The five codes of one coded image from its five histograms, by four waves: green, red, blue and alpha side
-// by side (wave 0 then adds the distance code); the sort of each is done by its wave, the joining of the tree
-// by the wave's first lane.  rc[c] < 0: that code failed (TooBigCodeLength).  Ends with a barrier.
+// by side (wave 0 then adds the distance code); sort, depths, lengths and codes of each are done by its wave, the joining of
+// the tree and the description by the wave's first lane.  rc[c] < 0: that code failed (TooBigCodeLength).  Ends with a barrier.
 // standard: codes of at most 15 bits (the histogram is then changed in place, huffman_lengths_limited).
 // describe: a wave's first lane also writes the description of each code it has built (vp8l.h:536-540) into the code's
 // own bit buffer dbuf[c] (dbits[c] bits, drc[c] = status), so the five descriptions are written side by side.
@@ -1658,13 +1754,16 @@ __device__ __forceinline__ void build_codes_4waves(uint32_t *histo5, CodeTables 
     uint32_t *h = histo5 + c * kCodeStride;
     uint8_t *len = t.len + c * kCodeStride;
     const int used = wave_prepare_leaves(h, nsym, hs, lane);
+    int u = wave_huffman_lengths(h, nsym, standard ? dialect_of(true).max_len : kMaxCodeLen, len, hs, used, lane);
+    if (standard && u == -3) {  // too long for the standard dialect: one lane raises the small counts until it fits (rare)
+      if (lane == 0) u = huffman_lengths_limited(h, nsym, dialect_of(true).max_len, len, hs);
+      u = __builtin_amdgcn_readfirstlane(u);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (u >= 0) wave_canonical_codes(len, nsym, t.code + c * kCodeStride, hs.wt, lane);
     if (lane == 0) {
-      const int u = standard ? huffman_lengths_limited(h, nsym, dialect_of(true).max_len, len, hs, used) : huffman_lengths(h, nsym, kMaxCodeLen, len, hs, used);
       rc[c] = u;
-      if (u >= 0) {
-        t.used[c] = (uint32_t)u;
-        canonical_reversed_codes(len, nsym, t.code + c * kCodeStride, hs.wt);
-      }
+      if (u >= 0) t.used[c] = (uint32_t)u;
       if (dbuf) {
         BitSink b;
         b.init(dbuf[c]);
@@ -1796,13 +1895,14 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
   // the main image: its histogram into the place the sub-images' had (the loop above ends with a barrier)
   for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) sh.sub.histo[i] = g[i];
   __syncthreads();
-  build_codes_4waves(sh.sub.histo, sh.sub.tables, sh.rc, ds, wave, lane, standard != 0, sh.dbuf, sh.dbits, sh.drc);
+  uint32_t (*dbuf)[kDescBufWords] = reinterpret_cast<uint32_t (*)[kDescBufWords]>(&sh.sub.lz);
+  build_codes_4waves(sh.sub.histo, sh.sub.tables, sh.rc, ds, wave, lane, standard != 0, dbuf, sh.dbits, sh.drc);
   if (tid == 0) {
     int rc = s_rc;
     if (rc == 0) write_stream_tail(bw);
     for (int c = 0; c < kNumCodes && rc == 0; c++) {  // vp8l.h:536-540
       rc = sh.drc[c];
-      const uint32_t *w = sh.dbuf[c];
+      const uint32_t *w = dbuf[c];
       uint32_t left = rc == 0 ? sh.dbits[c] : 0u;
       for (; left >= 32; left -= 32) bw.put(*w++, 32);
       if (left) bw.put(*w & ((1u << left) - 1u), left);
