@@ -2953,6 +2953,15 @@ extern "C" int vp8l_debug_dominant_reasons(unsigned int *out4) {
 }
 
 #ifdef VP8L_PHASE_TIMING
+// Measurement builds only: what k_lz77_walk did since the last call (then cleared); see g_wk_stat.
+extern "C" int vp8l_debug_walk_stats(unsigned long long *out8) {
+  if (!out8) return VP8L_ERR_BAD_ARGUMENT;
+  if (!hip_ok(hipDeviceSynchronize(), "sync")) return VP8L_ERR_HIP;
+  if (!hip_ok(hipMemcpyFromSymbol(out8, HIP_SYMBOL(vp8l::g_wk_stat), 8 * sizeof(unsigned long long)), "read stats")) return VP8L_ERR_HIP;
+  unsigned long long zero[8] = {};
+  if (!hip_ok(hipMemcpyToSymbol(HIP_SYMBOL(vp8l::g_wk_stat), zero, sizeof(zero)), "clear stats")) return VP8L_ERR_HIP;
+  return VP8L_OK;
+}
 // Measurement builds only: cycles per phase of k_lz77_sparse summed over the workgroups since the last call (then cleared).
 extern "C" int vp8l_debug_dominant_phase_cycles(unsigned long long *out12) {
   if (!hip_ok(hipDeviceSynchronize(), "sync")) return VP8L_ERR_HIP;

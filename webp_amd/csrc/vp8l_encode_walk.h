@@ -36,6 +36,14 @@ constexpr uint32_t kWkBudget = 20000;                              // rounds + e
 constexpr uint8_t kTileDoneWalk = 6;                               // tile flag: searched here, along the parse
 static_assert(kWkParts == 12 && kWkPart * kWkParts == kWkSources && kWkPart == 256 && kWkThreads == 256, "parts of 256 positions; a thread per byte value");
 
+#ifdef VP8L_PHASE_TIMING
+// measurement builds: tiles, positions searched, rounds of candidates, rounds with a live candidate, extension steps, tiles given up
+__device__ unsigned long long g_wk_stat[8];
+#define WK_STAT(k, n) do { if (lane == 0) atomicAdd(&g_wk_stat[k], (unsigned long long)(n)); } while (0)
+#else
+#define WK_STAT(k, n) do {} while (0)
+#endif
+
 struct WkShared {
   uint32_t by4[kWkWords];
   uint16_t list[kWkSources];              // window indices, grouped by (value, part)
@@ -157,12 +165,15 @@ __device__ __forceinline__ bool lz77_walk_tile(WkShared &S, const DmGeo &G, cons
       uint32_t stop_at = ce;
       uint32_t best = 0;
       const uint32_t t0 = wk_bytes(S.by4, ip);
+      WK_STAT(1, 1);
       for (uint32_t c = cs; c < stop_at; c += 64) {
         spent++;
+        WK_STAT(2, 1);
         const uint32_t idx = c + lane;
         const uint32_t q = idx < ce ? S.list[idx] : 0xffffu;
         const bool live = q < ip && q + kWindow >= ip;
         if (!__ballot(live)) continue;
+        WK_STAT(3, 1);
         const uint32_t d = ip - q, cap = d < rem ? d : rem;  // (meaningless in lanes that are not live)
         uint32_t l = 0;
         bool open = live;
@@ -172,6 +183,7 @@ __device__ __forceinline__ bool lz77_walk_tile(WkShared &S, const DmGeo &G, cons
         }
         for (uint32_t k = 4; __ballot(open); k += 4) {
           spent++;
+          WK_STAT(4, 1);
           const uint32_t x = wk_bytes(S.by4, (open ? q : 0u) + k) ^ wk_bytes(S.by4, ip + k);
           if (open) {
             if (x) { l = k + ((uint32_t)__builtin_ctz(x) >> 3); open = false; }
@@ -202,6 +214,7 @@ __device__ __forceinline__ bool lz77_walk_tile(WkShared &S, const DmGeo &G, cons
   }
   __syncthreads();
   const bool ok = S.abort_flag == 0;
+  if (tid == 0) { WK_STAT(0, 1); WK_STAT(5, ok ? 0 : 1); }
   if (ok && tid == 0) dense_tile[(pos0 + a) / kLzTile] = kTileDoneWalk;
   __syncthreads();  // (the flag is read before the next tile clears it)
   return ok;
