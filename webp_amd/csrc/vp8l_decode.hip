@@ -1024,6 +1024,10 @@ struct ParImage {
   uint32_t active;
   int32_t status;
   uint32_t total, xsize;
+  uint32_t tag;        // mode 1, images of at most 2^24 pixels whose alpha code has one symbol: 0x100 | a byte that is no pixel's alpha.  A
+                       // pixel that a reference makes is then kept in the image itself until its chain is resolved, as tag byte << 24 |
+                       // position of its source, and the per-pixel source array is not used (4 bytes less written per literal, one store
+                       // and one read less per copied pixel); 0: not so
   uint32_t fold_green; // the transform to undo first is subtract green: literals are stored with green added (copies then carry it), the pass is dropped
   uint64_t P0;         // stream position of the first token, in bits
   uint32_t *dst;
@@ -1035,6 +1039,15 @@ __device__ __forceinline__ uint64_t par_window_bits(const VP8L_LDS uint32_t *win
   const uint32_t idx = a >> 5, sft = a & 31u;
   const uint64_t x = (uint64_t)win[idx] | ((uint64_t)win[idx + 1] << 32);
   return sft ? (x >> sft) | ((uint64_t)win[idx + 2] << (64 - sft)) : x;
+}
+
+// ParImage::tag for an image whose alpha code's only symbol is alpha_single (0xffff: it has several) and that has `total` pixels
+__device__ __forceinline__ uint32_t par_pixel_tag(uint32_t alpha_single, uint64_t total) {
+#ifdef VP8L_NO_PIXEL_TAGS
+  return 0u;
+#else
+  return alpha_single != 0xffffu && total <= (1ull << 24) ? 0x100u | ((alpha_single ^ 0x80u) & 0xffu) : 0u;
+#endif
 }
 
 __device__ __forceinline__ void par_fail(ParImage *par, int32_t code) {
@@ -1669,7 +1682,11 @@ __global__ __launch_bounds__(kPlaceThreads) void k_par_place(const DecImage *__r
   uint32_t before_part[kLanesPerSeg];
 #pragma unroll
   for (uint32_t j = 0; j < kLanesPerSeg; j++) before_part[j] = parts ? (uint32_t)slot[4 + j] : 0u;
-  uint32_t *dst = par->dst, *srcg = par->srcg;
+  // with pixel tags (ParImage::tag) the sources go into the image itself, marked by the tag byte; else into the source array, where
+  // a position that holds its value is marked by kFinalBit
+  const uint32_t tagword = (par->tag & 0x100u) ? (par->tag & 0xffu) << 24 : 0u;
+  const bool tagged = (par->tag & 0x100u) != 0;
+  uint32_t *dst = par->dst, *srcg = tagged ? par->dst : par->srcg;
   const bool fold_green = par->fold_green != 0;
   bool bad = false;
   auto record = [&](uint32_t i) -> uint64_t {  // token i of the segment
@@ -1726,15 +1743,16 @@ __global__ __launch_bounds__(kPlaceThreads) void k_par_place(const DecImage *__r
         else if (ref[j] && val[j] > pos) bad = true; // a reference before the start of the image
         else {
           if (!ref[j]) dst[pos] = fold_green ? add_green(val[j]) : val[j];
-          srcg[pos] = ref[j] ? pos - val[j] : pos | kFinalBit;
+          if (ref[j]) srcg[pos] = tagword | (pos - val[j]);
+          else if (!tagged) srcg[pos] = pos | kFinalBit;
           expand = ref[j] && cnt[j] > 1;
         }
       }
       if (expand && cnt[j] <= kWgOwnCopy) {
         if (val[j] >= cnt[j]) {
-          for (uint32_t e = 1; e < cnt[j]; e++) srcg[pos + e] = pos - val[j] + e;
+          for (uint32_t e = 1; e < cnt[j]; e++) srcg[pos + e] = tagword | (pos - val[j] + e);
         } else {
-          for (uint32_t e = 1; e < cnt[j]; e++) srcg[pos + e] = pos - val[j] + e % val[j];
+          for (uint32_t e = 1; e < cnt[j]; e++) srcg[pos + e] = tagword | (pos - val[j] + e % val[j]);
         }
       }
       uint64_t m = __ballot(expand && cnt[j] > kWgOwnCopy);
@@ -1744,7 +1762,7 @@ __global__ __launch_bounds__(kPlaceThreads) void k_par_place(const DecImage *__r
         const uint32_t p2 = lane_read(pos, l), n2 = lane_read(cnt[j], l), dist = lane_read(val[j], l);
         for (uint32_t c2 = 0; c2 < n2; c2 += 64) {
           const uint32_t e = c2 + lane;
-          if (e < n2) srcg[p2 + e] = p2 - dist + (dist < n2 ? e % dist : e);
+          if (e < n2) srcg[p2 + e] = tagword | (p2 - dist + (dist < n2 ? e % dist : e));
         }
       }
     }
@@ -1773,6 +1791,38 @@ __global__ __launch_bounds__(256) void k_par_jump(const DecImage *__restrict__ i
     // dependent read of a microsecond; one pixel after the other left a wave with one read in flight per lane).
     constexpr uint32_t kJumpBatch = 4;
     static_assert((kUnit / 256) % kJumpBatch == 0, "groups of pixels per thread");
+#ifndef VP8L_JUMP_HOPS
+#define VP8L_JUMP_HOPS 5
+#endif
+    if (par->mode == 1 && (par->tag & 0x100u)) {
+      // Pixel tags (ParImage::tag): a pixel that a reference made holds tag byte << 24 | position of its source until a hop
+      // finds a pixel without the tag, which is its value.  Read while its owner replaces it, a pixel is its old source, a
+      // nearer one or the value: all of them lead to the same literal.
+      const uint32_t tagbyte = par->tag & 0xffu;
+      for (uint32_t k0 = 0; k0 < kUnit / 256; k0 += kJumpBatch) {
+        uint32_t t[kJumpBatch];
+        bool mine[kJumpBatch];
+#pragma unroll
+        for (uint32_t j = 0; j < kJumpBatch; j++) {
+          const uint64_t p = p0 + (k0 + j) * 256 + threadIdx.x;
+          t[j] = p < total ? dst[p] : (tagbyte ^ 0xffu) << 24;
+          mine[j] = (t[j] >> 24) == tagbyte;
+        }
+#pragma unroll
+        for (int hop = 0; hop < VP8L_JUMP_HOPS; hop++) {
+#pragma unroll
+          for (uint32_t j = 0; j < kJumpBatch; j++)
+            if ((t[j] >> 24) == tagbyte) t[j] = __hip_atomic_load(&dst[t[j] & 0xffffffu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kJumpBatch; j++) {
+          if (!mine[j]) continue;
+          const uint64_t p = p0 + (k0 + j) * 256 + threadIdx.x;
+          __hip_atomic_store(&dst[p], t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((t[j] >> 24) == tagbyte) open = true;
+        }
+      }
+    } else
     for (uint32_t k0 = 0; k0 < kUnit / 256; k0 += kJumpBatch) {
       uint32_t t[kJumpBatch];
       bool mine[kJumpBatch];  // a pixel whose chain is still open
@@ -1784,9 +1834,6 @@ __global__ __launch_bounds__(256) void k_par_jump(const DecImage *__restrict__ i
       }
       // the source's own source, several steps on; read while its owner replaces it, it is the old or the new one: both
       // lead to the same literal
-#ifndef VP8L_JUMP_HOPS
-#define VP8L_JUMP_HOPS 5
-#endif
 #pragma unroll
       for (int hop = 0; hop < VP8L_JUMP_HOPS; hop++) {
 #pragma unroll
@@ -1872,6 +1919,7 @@ __global__ __launch_bounds__(kWgThreads) void k_decode_entropy_wg(const DecImage
           // which saves a pass over the image.  (A stream the segment kernels hand back is decoded again from the start.)
           par->fold_green = st.nxf && st.xf[st.nxf - 1].type == 2 ? 1u : 0u;
           if (par->fold_green) st.nxf--;
+          par->tag = par_pixel_tag(g0.t[kAlpha].single, st.total);
           st.status = kParPending;
         }
         __syncthreads();
@@ -1965,6 +2013,7 @@ __global__ __launch_bounds__(64) void k_decode_headers(const DecImage *__restric
             par->active = 1;
             par->fold_green = st.nxf && st.xf[st.nxf - 1].type == 2 ? 1u : 0u;  // see k_decode_entropy_wg
             if (par->fold_green) st.nxf--;
+            par->tag = par_pixel_tag(g0.t[kAlpha].single, st.total);
             st.status = kParPending;
           }
           __syncthreads();
