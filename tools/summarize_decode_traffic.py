@@ -36,3 +36,16 @@ json.dump({"workload": {"batch": batch, "width": w, "height": h}, "kernels_all_c
            "command": "rocprofv3 --pmc <counter> --kernel-include-regex 'k_par_|k_decode_headers|k_decode_entropy|k_inverse' -- python3 bench.py --workload decode1080p --steps 1 --warmup 0 --no-cpu"},
           open(os.path.join(root, "profiles", tag + "_pmc_decode1080p.json"), "w"), indent=1)
 print(json.dumps(kernels, indent=1))
+
+# What bench.py reports as the decode roofline's traffic: one call's bytes.  Reads doubled where the kernel streams 16 bytes per
+# lane (scouts, placing: see above), raw elsewhere; writes as counted.
+calls = max(1, fl.get("k_par_scout_lanes", 1))
+doubled = ("k_par_scout_lanes", "k_par_place")
+f_total = sum((2.0 if k in doubled else 1.0) * v for k, v in fetch.items()) / calls
+w_total = sum(write.values()) / calls
+json.dump({"batch": batch, "width": w, "height": h, "hbm_bytes_per_call": f_total + w_total, "fetch_bytes": f_total, "write_bytes": w_total,
+           "note": "FETCH_SIZE doubled for k_par_scout_lanes and k_par_place (16-byte-per-lane streaming reads, the gfx950 correction); raw for "
+                   "k_par_jump (4-byte reads at random: uncalibrated); WRITE_SIZE as counted: the scouts' 16-byte record stores, one line per "
+                   "lane, are counted as whole 64-byte requests (17 GB for about 5 GB of records)",
+           "source": "profiles/%s_pmc_decode1080p.json" % tag},
+          open(os.path.join(root, "profiles", "decode_traffic.json"), "w"), indent=1)

@@ -1190,6 +1190,11 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
      }
     }
     (void)collect_and_score(aux + wave * kSpWaveAux, std::false_type{}, std::false_type{}, open_positions);
+    VP8L_PHASE_MARK(4);  // the search (and the results stored as they are known)
+#ifdef VP8L_PHASE_TIMING
+    __syncthreads();     // (measurement builds only: the waves of these tiles do not wait for one another otherwise)
+    VP8L_PHASE_MARK(5);
+#endif
     return;
   }
   // ---- tiles with runs: candidates are scored where they are found.  (Collecting them first, as above, made these
