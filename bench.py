@@ -56,12 +56,13 @@ def stage_bytes_per_pixel(bpp, palette_share=0.0, predictor=False):
         "palette": 4.0 * palette_share,
         "transform": transform,
         "match": 13.0,                       # 4 read; residual 4 + match 4 + advance 1 written
-        # advances read twice, block exits, token-start bits written; residual + match read to count the symbols
-        "parse": 2.0 + 1.0 / 8 + 1.0 / 128 + 8.0,
+        # advances read twice, block exits, token-start bits written; residual + match read to count the symbols; the symbol
+        # counts of every unit of 4096 positions written (1400 x 2 bytes)
+        "parse": 2.0 + 1.0 / 8 + 1.0 / 128 + 8.0 + 2800.0 / 4096,
         "histogram": 0.0,                    # the default coder counts inside "parse"; only the extended coder has this stage
         "header": 0.0,                       # per image, not per pixel
-        "bitcount_scan": 8.0 + 2.0 / 8,      # residual + match + bits read, bit counts per 16 positions written
-        "emit": 8.0 + 2.0 / 8 + bpp / 8.0,   # the same read again, the stream written
+        "bitcount_scan": 2800.0 / 4096,      # the units' symbol counts read (their bits are a sum over the symbols: no pass over the pixels)
+        "emit": 8.0 + 1.0 / 8 + bpp / 8.0,   # residual + match + token-start bits read, the stream written
     }
 
 

@@ -262,6 +262,8 @@ struct CodeTables {
   uint32_t code[kNumCodes * kCodeStride];
   uint8_t len[kNumCodes * kCodeStride];
   uint32_t used[kNumCodes];  // number of symbols with non-zero count
+  uint8_t wbits[kNumCodes * kCodeStride];  // GPU encoder: bits one occurrence of the symbol takes in the stream (0 for a code that is not
+                                           // written, plus the extra bits behind a length or distance prefix); filled by k_entropy_header
 };
 
 // Builds the five codes from the five histograms and writes their descriptions

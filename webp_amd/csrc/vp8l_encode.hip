@@ -1501,7 +1501,8 @@ __global__ __launch_bounds__(kMarkThreads) void k_parse_mark(const EncImage *__r
                                                              const uint32_t *__restrict__ sb_first, uint32_t n,
                                                              const uint8_t *__restrict__ adv8, const uint8_t *__restrict__ entry,
                                                              uint32_t *__restrict__ flags, const uint32_t *__restrict__ pix,
-                                                             const uint32_t *__restrict__ match, uint32_t *__restrict__ histo) {
+                                                             const uint32_t *__restrict__ match, uint32_t *__restrict__ histo,
+                                                             uint8_t *__restrict__ unit_hist) {
   constexpr uint32_t kAdvBytes = kBlocksPerSuper * kRowPad, kHistWords = kNumCodes * kCodeStride * kHistCopies;
   static_assert(kHistWords * 4 <= kAdvBytes, "the histogram fits where the advances were");
   __shared__ __attribute__((aligned(16))) uint8_t adv[kAdvBytes];  // exits first, then the advances again, then the histogram
@@ -1536,64 +1537,88 @@ __global__ __launch_bounds__(kMarkThreads) void k_parse_mark(const EncImage *__r
   }
   if (!histo) return;  // the coder with several groups counts by itself
   __syncthreads();
+  // The symbols are counted unit by unit (kUnit positions; a token belongs to the unit it starts in).  unit_hist (may be null):
+  // the counts of every unit are left, 16 bits each, where the unit's advances were (this workgroup has read its superblock's
+  // advances for the last time, and nobody else reads them): with them, the bits of a unit are a sum over the symbols of
+  // count x (code length + extra bits) once the codes are known (k_unit_bits), instead of another pass over pixels and matches.
   uint32_t *h = reinterpret_cast<uint32_t *>(adv);
+  constexpr uint32_t kCounters = kNumCodes * kCodeStride, kMine = (kCounters + kMarkThreads - 1) / kMarkThreads;
+  static_assert(kCounters * 2 <= kUnit, "a unit's counts fit where its advances were");
+  uint32_t tot[kMine];
+#pragma unroll
+  for (uint32_t j = 0; j < kMine; j++) tot[j] = 0;
   for (uint32_t i = tid; i < kHistWords; i += kMarkThreads) h[i] = 0;
   __syncthreads();
-  // four consecutive positions per thread, everything loaded before anything is used (the arrays have readable slack past M)
+#pragma unroll 1
+  for (uint32_t u = 0; u < kUnitsPerSuper && p0 + u * kUnit < M; u++) {
+    // four consecutive positions per thread, everything loaded before anything is used (the arrays have readable slack past M)
 #pragma unroll 2
-  for (uint32_t k = 0; k < kSuper / (4 * kMarkThreads); k++) {
-    const uint32_t o = (k * kMarkThreads + tid) * 4, p = p0 + o;
-    if (p >= M) break;
-    uint32_t f4 = (fl[o >> 5] >> (o & 31)) & 15u;
-    if (p + 4 > M) f4 &= (1u << (M - p)) - 1u;
-    if (!f4) continue;
-    const uint4 m4 = *reinterpret_cast<const uint4 *>(match + pos0 + p);
-    const uint4 x4 = *reinterpret_cast<const uint4 *>(pix + pos0 + p);
-    const uint32_t mm[4] = {m4.x, m4.y, m4.z, m4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
+    for (uint32_t kk = 0; kk < kUnit / (4 * kMarkThreads); kk++) {
+      const uint32_t o = u * kUnit + (kk * kMarkThreads + tid) * 4, p = p0 + o;
+      uint32_t f4 = p < M ? (fl[o >> 5] >> (o & 31)) & 15u : 0u;
+      if (p < M && p + 4 > M) f4 &= (1u << (M - p)) - 1u;
+      if (!f4) continue;
+      const uint4 m4 = *reinterpret_cast<const uint4 *>(match + pos0 + p);
+      const uint4 x4 = *reinterpret_cast<const uint4 *>(pix + pos0 + p);
+      const uint32_t mm[4] = {m4.x, m4.y, m4.z, m4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (!((f4 >> j) & 1u)) continue;
-      const uint32_t m = mm[j], len = m & 0xff;
-      if (len == 0) {
-        // One count per channel and active lane.  Lanes that all hold the same pixel (a flat area) or the same alpha (an
-        // opaque image) would serialise on one LDS address: then one lane adds the number of lanes.  One test per pixel
-        // and one for alpha: the other channels of a pixel that differs somewhere spread over the counters' copies.
-        const uint32_t px = xx[j];
-        const uint64_t active = __ballot(1);
-        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)px), diff = px ^ first;
-        const bool leader = (uint32_t)__builtin_ctzll(active) == (tid & 63u);
-        const uint32_t lanes = (uint32_t)__popcll(active), copy = tid % kHistCopies;
-        if (!__ballot(diff != 0)) {
-          if (leader) {
-            atomicAdd(&h[(kGreen * kCodeStride + ((first >> 8) & 0xff)) * kHistCopies], lanes);
-            atomicAdd(&h[(kRed * kCodeStride + ((first >> 16) & 0xff)) * kHistCopies], lanes);
-            atomicAdd(&h[(kBlue * kCodeStride + (first & 0xff)) * kHistCopies], lanes);
-            atomicAdd(&h[(kAlpha * kCodeStride + (first >> 24)) * kHistCopies], lanes);
+      for (int j = 0; j < 4; j++) {
+        if (!((f4 >> j) & 1u)) continue;
+        const uint32_t m = mm[j], len = m & 0xff;
+        if (len == 0) {
+          // One count per channel and active lane.  Lanes that all hold the same pixel (a flat area) or the same alpha (an
+          // opaque image) would serialise on one LDS address: then one lane adds the number of lanes.  One test per pixel
+          // and one for alpha: the other channels of a pixel that differs somewhere spread over the counters' copies.
+          const uint32_t px = xx[j];
+          const uint64_t active = __ballot(1);
+          const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)px), diff = px ^ first;
+          const bool leader = (uint32_t)__builtin_ctzll(active) == (tid & 63u);
+          const uint32_t lanes = (uint32_t)__popcll(active), copy = tid % kHistCopies;
+          if (!__ballot(diff != 0)) {
+            if (leader) {
+              atomicAdd(&h[(kGreen * kCodeStride + ((first >> 8) & 0xff)) * kHistCopies], lanes);
+              atomicAdd(&h[(kRed * kCodeStride + ((first >> 16) & 0xff)) * kHistCopies], lanes);
+              atomicAdd(&h[(kBlue * kCodeStride + (first & 0xff)) * kHistCopies], lanes);
+              atomicAdd(&h[(kAlpha * kCodeStride + (first >> 24)) * kHistCopies], lanes);
+            }
+          } else {
+            atomicAdd(&h[(kGreen * kCodeStride + ((px >> 8) & 0xff)) * kHistCopies + copy], 1u);
+            atomicAdd(&h[(kRed * kCodeStride + ((px >> 16) & 0xff)) * kHistCopies + copy], 1u);
+            atomicAdd(&h[(kBlue * kCodeStride + (px & 0xff)) * kHistCopies + copy], 1u);
+            if (!__ballot((diff >> 24) != 0)) {
+              if (leader) atomicAdd(&h[(kAlpha * kCodeStride + (first >> 24)) * kHistCopies], lanes);
+            } else {
+              atomicAdd(&h[(kAlpha * kCodeStride + (px >> 24)) * kHistCopies + copy], 1u);
+            }
           }
         } else {
-          atomicAdd(&h[(kGreen * kCodeStride + ((px >> 8) & 0xff)) * kHistCopies + copy], 1u);
-          atomicAdd(&h[(kRed * kCodeStride + ((px >> 16) & 0xff)) * kHistCopies + copy], 1u);
-          atomicAdd(&h[(kBlue * kCodeStride + (px & 0xff)) * kHistCopies + copy], 1u);
-          if (!__ballot((diff >> 24) != 0)) {
-            if (leader) atomicAdd(&h[(kAlpha * kCodeStride + (first >> 24)) * kHistCopies], lanes);
-          } else {
-            atomicAdd(&h[(kAlpha * kCodeStride + (px >> 24)) * kHistCopies + copy], 1u);
-          }
+          uint32_t sym, nb, eb;
+          prefix_encode(len, sym, nb, eb);
+          atomicAdd(&h[(kGreen * kCodeStride + 256 + sym) * kHistCopies + (tid % kHistCopies)], 1u);
+          prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);  // distance code, computed with the match
+          atomicAdd(&h[(kDist * kCodeStride + sym) * kHistCopies + (tid % kHistCopies)], 1u);
         }
-      } else {
-        uint32_t sym, nb, eb;
-        prefix_encode(len, sym, nb, eb);
-        atomicAdd(&h[(kGreen * kCodeStride + 256 + sym) * kHistCopies + (tid % kHistCopies)], 1u);
-        prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);  // distance code, computed with the match
-        atomicAdd(&h[(kDist * kCodeStride + sym) * kHistCopies + (tid % kHistCopies)], 1u);
       }
     }
+    __syncthreads();
+    uint16_t *uh = unit_hist ? reinterpret_cast<uint16_t *>(unit_hist + pos0 + p0 + u * kUnit) : nullptr;
+#pragma unroll
+    for (uint32_t j = 0; j < kMine; j++) {
+      const uint32_t i = j * kMarkThreads + tid;
+      if (i < kCounters) {
+        const uint32_t v = h[i * kHistCopies] + h[i * kHistCopies + 1] + h[i * kHistCopies + 2];
+        h[i * kHistCopies] = 0; h[i * kHistCopies + 1] = 0; h[i * kHistCopies + 2] = 0;  // for the next unit
+        tot[j] += v;
+        if (uh) uh[i] = (uint16_t)v;
+      }
+    }
+    __syncthreads();  // the counters are clear before the next unit counts
   }
-  __syncthreads();
   uint32_t *g = histo + (size_t)img * kNumCodes * kCodeStride;
-  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += kMarkThreads) {
-    const uint32_t v = h[i * kHistCopies] + h[i * kHistCopies + 1] + h[i * kHistCopies + 2];
-    if (v) atomicAdd(&g[i], v);
+#pragma unroll
+  for (uint32_t j = 0; j < kMine; j++) {
+    const uint32_t i = j * kMarkThreads + tid;
+    if (i < kCounters && tot[j]) atomicAdd(&g[i], tot[j]);
   }
 }
 
@@ -1782,6 +1807,12 @@ __device__ __forceinline__ void build_codes_4waves(uint32_t *histo5, CodeTables 
   __syncthreads();
 }
 
+// index i of the 5 x kCodeStride tables belongs to a code whose symbols are not written
+__device__ __forceinline__ bool code_unwritten(const CodeTables *T, uint32_t i) {
+  const uint32_t c = i / kCodeStride, sym = i % kCodeStride;
+  return T->used[c] <= 1 && !(c == (uint32_t)kGreen && sym >= 256);
+}
+
 // Per image: the codes and every bit in front of the first token.  The parts with many independent items
 // (palette matches, sorting) use the workgroup; the bits are written by one lane, in stream order.
 __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
@@ -1916,6 +1947,14 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
     st[img].hdr_bits = (uint32_t)bw.bits();
     st[img].status = rc;
   }
+  // what one occurrence of every symbol costs in bits (k_unit_bits multiplies the units' symbol counts with it)
+  for (uint32_t i = tid; i < kNumCodes * kCodeStride; i += 256) {
+    const uint32_t c = i / kCodeStride, sym = i % kCodeStride;
+    uint32_t w = code_unwritten(&sh.sub.tables, i) ? 0u : sh.sub.tables.len[i];
+    const uint32_t prefix = c == (uint32_t)kGreen && sym >= 256 ? sym - 256 : c == (uint32_t)kDist ? sym : 0u;
+    if (prefix >= 4) w += (prefix - 2) >> 1;  // extra bits of a prefix symbol (lz77.cpp:89-102)
+    sh.sub.tables.wbits[i] = (uint8_t)w;
+  }
   __syncthreads();
   const uint32_t *src = reinterpret_cast<const uint32_t *>(&sh.sub.tables);
   uint32_t *dst = reinterpret_cast<uint32_t *>(&tables[img]);
@@ -1939,12 +1978,6 @@ __device__ __forceinline__ uint32_t token_bit_count(const uint8_t *lens, uint32_
   bits = lens[kGreen * kCodeStride + 256 + sym] + nb;
   prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);
   return bits + nb + lens[kDist * kCodeStride + sym];
-}
-
-// index i of the 5 x kCodeStride tables belongs to a code whose symbols are not written
-__device__ __forceinline__ bool code_unwritten(const CodeTables *T, uint32_t i) {
-  const uint32_t c = i / kCodeStride, sym = i % kCodeStride;
-  return T->used[c] <= 1 && !(c == (uint32_t)kGreen && sym >= 256);
 }
 
 // sum over 4 adjacent lanes, valid in the last of them
@@ -1997,6 +2030,40 @@ __global__ __launch_bounds__(256) void k_bitcount(const EncImage *__restrict__ i
   if ((tid & 63) == 0) wsum[tid >> 6] = s;
   __syncthreads();
   if (tid == 0) unit_bits[unit] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// The same unit sums from the symbol counts that k_parse_mark left per unit (16 bits each, where the unit's advances were):
+// bits of a unit = sum over the symbols of count x (code length, or nothing for a code that is not written, + the extra bits
+// that follow a length or distance prefix).  A superblock per workgroup: 2.8 KB read per unit instead of 8 bytes per position.
+constexpr uint32_t kUnitBitsThreads = 192;
+__global__ __launch_bounds__(kUnitBitsThreads) void k_unit_bits(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+                                                                const uint32_t *__restrict__ sb_first, uint32_t n,
+                                                                const uint8_t *__restrict__ unit_hist, const CodeTables *__restrict__ tables,
+                                                                uint32_t *__restrict__ unit_bits) {
+  constexpr uint32_t kCounters = kNumCodes * kCodeStride;
+  static_assert(kCounters % 8 == 0 && kCounters / 8 <= kUnitBitsThreads, "eight counters (one 16-byte load) per thread");
+  __shared__ uint32_t wsum[kUnitBitsThreads / 64];
+  const uint32_t sb = blockIdx.x, img = find_image(sb_first, n, sb), tid = threadIdx.x;
+  const uint32_t M = st[img].M;
+  const uint32_t p0 = (sb - sb_first[img]) * kSuper;
+  if (p0 >= M) return;
+  const bool mine = tid < kCounters / 8;
+  uint2 w8 = make_uint2(0, 0);  // the bits of this thread's eight symbols, a byte each (CodeTables::wbits)
+  if (mine) w8 = reinterpret_cast<const uint2 *>(tables[img].wbits)[tid];
+  const uint64_t pos0 = imgs[img].pos0;
+  for (uint32_t u = 0; u < kUnitsPerSuper && p0 + u * kUnit < M; u++) {
+    uint32_t bits = 0;
+    if (mine) {
+      const uint4 c = reinterpret_cast<const uint4 *>(unit_hist + pos0 + p0 + u * kUnit)[tid];
+      bits = (c.x & 0xffffu) * (w8.x & 0xffu) + (c.x >> 16) * ((w8.x >> 8) & 0xffu) + (c.y & 0xffffu) * ((w8.x >> 16) & 0xffu) + (c.y >> 16) * (w8.x >> 24) +
+             (c.z & 0xffffu) * (w8.y & 0xffu) + (c.z >> 16) * ((w8.y >> 8) & 0xffu) + (c.w & 0xffffu) * ((w8.y >> 16) & 0xffu) + (c.w >> 16) * (w8.y >> 24);
+    }
+    const uint32_t sum = wave_sum_u32(bits);
+    if ((tid & 63) == 0) wsum[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) unit_bits[sb * kUnitsPerSuper + u] = wsum[0] + wsum[1] + wsum[2];
+    __syncthreads();
+  }
 }
 
 // Exclusive scan of the unit bit counts of one image (starting at the header length).  Also clears
@@ -2117,6 +2184,45 @@ __device__ __forceinline__ void emit_token_packed(Put &put, const uint2 *tab, ui
   }
 }
 
+// Bits of one token, from the same table (the lengths of emit_token_packed's four parts and the extra bits).
+__device__ __forceinline__ uint32_t token_bits_packed(const uint2 *tab, uint32_t pixel, uint32_t m) {
+  const uint32_t len = m & 0xff;
+  uint32_t i0 = kGreen * kCodeStride + ((pixel >> 8) & 0xff), i1 = kRed * kCodeStride + ((pixel >> 16) & 0xff);
+  uint32_t i2 = kBlue * kCodeStride + (pixel & 0xff), i3 = kAlpha * kCodeStride + (pixel >> 24);
+  uint32_t extra = 0;
+  if (len) {
+    uint32_t sym, nb, eb;
+    prefix_encode(len, sym, nb, eb);
+    i0 = kGreen * kCodeStride + 256 + sym;
+    extra = nb;
+    prefix_encode((m >> 19) & 0x7ff, sym, nb, eb);
+    i2 = kDist * kCodeStride + sym;
+    extra += nb;
+    i1 = i3 = kTabZero;
+  }
+  return tab[i0].y + tab[i1].y + tab[i2].y + tab[i3].y + extra;
+}
+
+// Bits of the tokens of 16 consecutive positions (what k_bitcount leaves per group when it runs).
+__device__ __forceinline__ uint32_t count_group(const uint2 *tab, const uint32_t *__restrict__ px, const uint32_t *__restrict__ mt, uint32_t fl) {
+  uint4 m4[4], p4[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    m4[g] = reinterpret_cast<const uint4 *>(mt)[g];
+    p4[g] = reinterpret_cast<const uint4 *>(px)[g];
+  }
+  uint32_t bits = 0;
+#pragma unroll
+  for (int g = 0; g < 4; g++, fl >>= 4) {
+    if ((fl & 15u) == 0) continue;
+    if (fl & 1u) bits += token_bits_packed(tab, p4[g].x, m4[g].x);
+    if (fl & 2u) bits += token_bits_packed(tab, p4[g].y, m4[g].y);
+    if (fl & 4u) bits += token_bits_packed(tab, p4[g].z, m4[g].z);
+    if (fl & 8u) bits += token_bits_packed(tab, p4[g].w, m4[g].w);
+  }
+  return bits;
+}
+
 // The tokens of 16 consecutive positions; all eight 16-byte loads are issued before the first token is written.
 template <class Put>
 __device__ __forceinline__ void emit_group(Put &put, const uint2 *tab, const uint32_t *__restrict__ px,
@@ -2167,6 +2273,7 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
   const EncImage im = imgs[img];
   const uint64_t pos0 = im.pos0;
   uint32_t *out32 = reinterpret_cast<uint32_t *>(out + im.out_off);
+  if (!group_bits) __syncthreads();  // the tables are in LDS: the threads count their tokens' bits with them
   for (uint32_t u = 0; u < kUnitsPerSuper; u++) {
   const uint32_t unit = sb * kUnitsPerSuper + u;
   const uint32_t p0 = (sb - sb_first[img]) * kSuper + u * kUnit;
@@ -2178,7 +2285,10 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
   if (pb < M) {
     fl = (flags[(pos0 + pb) >> 5] >> ((pos0 + pb) & 31)) & 0xffffu;
     if (pb + 16 > M) fl &= (1u << (M - pb)) - 1u;
-    mybits = group_bits[(pos0 + pb) >> 4];
+    // group_bits: what k_bitcount counted for these 16 positions; null: no such pass was made (the units' sums come from the
+    // symbol counts, k_unit_bits), and the thread counts its own tokens here (it loads them again to write them: holding them
+    // in registers over the barriers in between made the kernel half as fast again)
+    mybits = group_bits ? group_bits[(pos0 + pb) >> 4] : count_group(tab, px, mt, fl);
   }
   const uint32_t incl = wave_incl_scan_u32(mybits, (int)lane);
   if (lane == 63) wsum[wave] = incl;
@@ -2310,7 +2420,8 @@ struct vp8l_encoder {
 };
 
 // Heuristics of the candidate-list kernel (when a tile goes to the exhaustive kernel instead); VP8L_TUNE="mean_bucket,budget,max_bucket,dense"
-// overrides them for measurements (dense: bit 0 = k_lz77_dominant runs, bit 1 = with its part for grams; every setting gives the same matches).
+// overrides them for measurements (dense: bit 0 = k_lz77_dominant runs, bit 1 = k_lz77_grams too, bit 2 = k_lz77_walk too, bit 3 = the
+// bits of the units are counted by a pass over pixels and matches, k_bitcount, as they used to be; every setting gives the same streams).
 static uint32_t g_tune[4] = {kSpMaxMeanBucket, kSpBudget, kSpMaxBucket, 1};
 static const bool g_tune_read = [] {
   const char *v = getenv("VP8L_TUNE");
@@ -2415,8 +2526,11 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   hipLaunchKernelGGL(k_parse_exits, dim3(gsb), dim3(128), 0, s, B.imgs, B.st, B.sbf, nl, B.adv8, B.sx);
   hipLaunchKernelGGL(k_parse_chain, dim3(nl), dim3(256), 0, s, B.st, B.sbf, B.sx, B.entry);
   const bool ext_on = extp && extp->on;
+  // the units' bit sums from the symbol counts of the units (k_unit_bits) instead of a pass over pixels and matches (k_bitcount);
+  // VP8L_TUNE's fourth value, bit 3: the pass
+  const bool unit_counts = !ext_on && !(g_tune[3] & 8u);
   hipLaunchKernelGGL(k_parse_mark, dim3(gsb), dim3(kMarkThreads), 0, s, B.imgs, B.st, B.sbf, nl, B.adv8, B.entry, B.flags, B.pix, B.match,
-                     ext_on ? (uint32_t *)nullptr : B.histo);
+                     ext_on ? (uint32_t *)nullptr : B.histo, unit_counts ? B.adv8 : (uint8_t *)nullptr);
   mark(4);
   ExtArgs ext;
   memset(&ext, 0, sizeof(ext));
@@ -2449,10 +2563,12 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   mark(5);  // the symbols were counted by k_parse_mark
   hipLaunchKernelGGL(k_entropy_header, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.histo, B.tables, B.modes, B.elems, d_out, standard, ext);
   mark(6);
-  hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables, B.gbits, B.ubits);
+  if (unit_counts) hipLaunchKernelGGL(k_unit_bits, dim3(gsb), dim3(kUnitBitsThreads), 0, s, B.imgs, B.st, B.sbf, nl, (const uint8_t *)B.adv8, B.tables, B.ubits);
+  else hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables, B.gbits, B.ubits);
   hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.sbf, B.ubits, B.uoff, d_out, standard);
   mark(7);
-  hipLaunchKernelGGL(k_emit, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables, B.gbits, B.uoff, d_out);
+  hipLaunchKernelGGL(k_emit, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables,
+                     unit_counts ? (const uint16_t *)nullptr : (const uint16_t *)B.gbits, B.uoff, d_out);
   }
   mark(8);
   if (!hip_ok(hipGetLastError(), "kernel launch")) return VP8L_ERR_HIP;
