@@ -2153,6 +2153,28 @@ struct RunPut {
   __device__ __forceinline__ void finish() { if (fill) atomicOr(&stage[w], (uint32_t)acc); }
 };
 
+// Writer for a thread's run into its private buffer, from bit 0: words beyond the buffer are dropped but counted.
+constexpr uint32_t kPrivWords = 12;                  // words of a thread's private run (16 tokens of 24 bits)
+constexpr uint32_t kPrivStride = kPrivWords + 1;     // odd: the threads' buffers start in different LDS banks
+struct PrivPut {
+  uint32_t *buf;
+  uint32_t w, fill;
+  unsigned long long acc;
+  __device__ __forceinline__ explicit PrivPut(uint32_t *b) : buf(b), w(0), fill(0), acc(0) {}
+  __device__ __forceinline__ void operator()(uint32_t v, uint32_t n) {
+    acc |= (unsigned long long)v << fill;
+    fill += n;
+    if (fill >= 32) {
+      if (w < kPrivWords) buf[w] = (uint32_t)acc;
+      w++;
+      acc >>= 32;
+      fill -= 32;
+    }
+  }
+  __device__ __forceinline__ void finish() { if (fill && w < kPrivWords) buf[w] = (uint32_t)acc; }
+  __device__ __forceinline__ uint32_t bits() const { return w * 32 + fill; }
+};
+
 // `tab` has (0, 0) for the codes that are not written and one more (0, 0) entry at kTabZero.  Literals and back
 // references differ only in where their four parts come from, so a wave with both kinds runs the lookups, the
 // assembly and the write once.  A token of at most 32 bits (nearly all) goes out in one piece.
@@ -2244,6 +2266,11 @@ __device__ __forceinline__ void emit_group(Put &put, const uint2 *tab, const uin
   put.finish();
 }
 
+// kPrivate: no bit counts per 16 positions exist (group_bits is null) and a thread does not count its tokens first either: it
+// writes its run into a private LDS buffer from bit 0, which tells its length; after the scan of the lengths the run is
+// shifted into the window (five instructions per word instead of twenty-five per token to count).  A run longer than the
+// buffer, or one that crosses a window edge, is written from the tokens again as in the other form.
+template <bool kPrivate>
 __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                               const uint32_t *__restrict__ sb_first, uint32_t n,
                                               const uint32_t *__restrict__ pix, const uint32_t *__restrict__ match,
@@ -2253,6 +2280,7 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
   __shared__ uint2 tab[kNumCodes * kCodeStride + 1];  // (code, length), and a zero entry
   __shared__ uint32_t stage[kWinWords + 2];
   __shared__ uint32_t wsum[4];
+  __shared__ uint32_t priv[kPrivate ? 256 * kPrivStride : 1];
   // one superblock (four units) per workgroup: the code tables are fetched into LDS once for 16384 positions
   const uint32_t sb = blockIdx.x, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -2273,7 +2301,7 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
   const EncImage im = imgs[img];
   const uint64_t pos0 = im.pos0;
   uint32_t *out32 = reinterpret_cast<uint32_t *>(out + im.out_off);
-  if (!group_bits) __syncthreads();  // the tables are in LDS: the threads count their tokens' bits with them
+  if (kPrivate || !group_bits) __syncthreads();  // the tables are in LDS: the threads count (or write) their tokens with them
   for (uint32_t u = 0; u < kUnitsPerSuper; u++) {
   const uint32_t unit = sb * kUnitsPerSuper + u;
   const uint32_t p0 = (sb - sb_first[img]) * kSuper + u * kUnit;
@@ -2288,7 +2316,13 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
     // group_bits: what k_bitcount counted for these 16 positions; null: no such pass was made (the units' sums come from the
     // symbol counts, k_unit_bits), and the thread counts its own tokens here (it loads them again to write them: holding them
     // in registers over the barriers in between made the kernel half as fast again)
-    mybits = group_bits ? group_bits[(pos0 + pb) >> 4] : count_group(tab, px, mt, fl);
+    if (kPrivate) {
+      PrivPut put(priv + tid * kPrivStride);
+      emit_group(put, tab, px, mt, fl);
+      mybits = put.bits();
+    } else {
+      mybits = group_bits ? group_bits[(pos0 + pb) >> 4] : count_group(tab, px, mt, fl);
+    }
   }
   const uint32_t incl = wave_incl_scan_u32(mybits, (int)lane);
   if (lane == 63) wsum[wave] = incl;
@@ -2309,7 +2343,18 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
     __syncthreads();
     const long long rel = (long long)my_bit - (long long)((first_word + wbase) << 5);
     if (mybits && rel + (long long)mybits > 0 && rel < kWinBits) {
-      if (rel >= 0 && rel + (long long)mybits <= kWinBits) {
+      if (kPrivate && rel >= 0 && rel + (long long)mybits <= kWinBits && mybits <= kPrivWords * 32) {
+        // the private run, shifted to its place: the first and the last word are shared with the neighbours' runs
+        const uint32_t *buf = priv + tid * kPrivStride;
+        const uint32_t sh = (uint32_t)rel & 31u, w0 = (uint32_t)rel >> 5, nw = (mybits + 31) >> 5, nout = (sh + mybits + 31) >> 5;
+        uint32_t prev = 0;
+        for (uint32_t j = 0; j < nout; j++) {
+          const uint32_t cur = j < nw ? buf[j] : 0u;
+          const uint32_t o = sh ? (cur << sh) | (prev >> (32 - sh)) : cur;
+          if (j == 0 || j == nout - 1) atomicOr(&stage[w0 + j], o); else stage[w0 + j] = o;
+          prev = cur;
+        }
+      } else if (rel >= 0 && rel + (long long)mybits <= kWinBits) {
         RunPut put(stage, (uint32_t)rel);
         emit_group(put, tab, px, mt, fl);
       } else {  // the run crosses a window edge
@@ -2421,7 +2466,8 @@ struct vp8l_encoder {
 
 // Heuristics of the candidate-list kernel (when a tile goes to the exhaustive kernel instead); VP8L_TUNE="mean_bucket,budget,max_bucket,dense"
 // overrides them for measurements (dense: bit 0 = k_lz77_dominant runs, bit 1 = k_lz77_grams too, bit 2 = k_lz77_walk too, bit 3 = the
-// bits of the units are counted by a pass over pixels and matches, k_bitcount, as they used to be; every setting gives the same streams).
+// bits of the units are counted by a pass over pixels and matches, k_bitcount, as they used to be, bit 4 = a thread of k_emit counts its
+// tokens before it writes them instead of writing them to a private buffer first; every setting gives the same streams).
 static uint32_t g_tune[4] = {kSpMaxMeanBucket, kSpBudget, kSpMaxBucket, 1};
 static const bool g_tune_read = [] {
   const char *v = getenv("VP8L_TUNE");
@@ -2567,8 +2613,12 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   else hipLaunchKernelGGL(k_bitcount, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables, B.gbits, B.ubits);
   hipLaunchKernelGGL(k_scan, dim3(nl), dim3(256), 0, s, B.imgs, B.st, B.sbf, B.ubits, B.uoff, d_out, standard);
   mark(7);
-  hipLaunchKernelGGL(k_emit, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables,
-                     unit_counts ? (const uint16_t *)nullptr : (const uint16_t *)B.gbits, B.uoff, d_out);
+  if (unit_counts && !(g_tune[3] & 16u))
+    hipLaunchKernelGGL(k_emit<true>, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables,
+                       (const uint16_t *)nullptr, B.uoff, d_out);
+  else
+    hipLaunchKernelGGL(k_emit<false>, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables,
+                       unit_counts ? (const uint16_t *)nullptr : (const uint16_t *)B.gbits, B.uoff, d_out);
   }
   mark(8);
   if (!hip_ok(hipGetLastError(), "kernel launch")) return VP8L_ERR_HIP;
