@@ -2271,12 +2271,12 @@ __device__ __forceinline__ void emit_group(Put &put, const uint2 *tab, const uin
 // shifted into the window (five instructions per word instead of twenty-five per token to count).  A run longer than the
 // buffer, or one that crosses a window edge, is written from the tokens again as in the other form.
 template <bool kPrivate>
-__global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
+__global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs, EncState *__restrict__ st,
                                               const uint32_t *__restrict__ sb_first, uint32_t n,
                                               const uint32_t *__restrict__ pix, const uint32_t *__restrict__ match,
                                               const uint32_t *__restrict__ flags, const CodeTables *__restrict__ tables,
-                                              const uint16_t *__restrict__ group_bits, const uint64_t *__restrict__ unit_off,
-                                              uint8_t *__restrict__ out) {
+                                              const uint16_t *__restrict__ group_bits, const uint32_t *__restrict__ unit_bits,
+                                              const uint64_t *__restrict__ unit_off, uint8_t *__restrict__ out) {
   __shared__ uint2 tab[kNumCodes * kCodeStride + 1];  // (code, length), and a zero entry
   __shared__ uint32_t stage[kWinWords + 2];
   __shared__ uint32_t wsum[4];
@@ -2331,6 +2331,13 @@ __global__ __launch_bounds__(256) void k_emit(const EncImage *__restrict__ imgs,
   for (uint32_t k = 0; k < wave; k++) before += wsum[k];
   const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
   __syncthreads();  // wsum is read before the next unit overwrites it
+  // The unit's place in the stream was made for unit_bits[unit] bits, counted another way (k_unit_bits from the symbol counts, or
+  // k_bitcount): they are the same number by construction, and writing any other number of bits would run into the neighbours
+  // or past the buffer - so nothing is written then and the image fails.
+  if (total != unit_bits[unit]) {
+    if (tid == 0) st[img].status = VP8L_ERR_HIP;
+    continue;
+  }
   if (total == 0) continue;
   const uint64_t start_bit = unit_off[unit], end_bit = start_bit + total;
   const uint64_t my_bit = start_bit + before + incl - mybits;
@@ -2615,10 +2622,10 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   mark(7);
   if (unit_counts && !(g_tune[3] & 16u))
     hipLaunchKernelGGL(k_emit<true>, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables,
-                       (const uint16_t *)nullptr, B.uoff, d_out);
+                       (const uint16_t *)nullptr, (const uint32_t *)B.ubits, B.uoff, d_out);
   else
     hipLaunchKernelGGL(k_emit<false>, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix, B.match, B.flags, B.tables,
-                       unit_counts ? (const uint16_t *)nullptr : (const uint16_t *)B.gbits, B.uoff, d_out);
+                       unit_counts ? (const uint16_t *)nullptr : (const uint16_t *)B.gbits, (const uint32_t *)B.ubits, B.uoff, d_out);
   }
   mark(8);
   if (!hip_ok(hipGetLastError(), "kernel launch")) return VP8L_ERR_HIP;
