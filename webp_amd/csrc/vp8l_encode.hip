@@ -712,6 +712,8 @@ constexpr uint8_t kTileExhaustive = 1, kTilePairs = 2;
 constexpr uint32_t kFewListAt = 14;
 __device__ __forceinline__ void give_up_tile(uint8_t *__restrict__ dense_tile, uint32_t *__restrict__ given_up, uint32_t tile) {
   dense_tile[tile] = kTileExhaustive;
+  // (additions to one address go one after another, 11 ns each; counting one tile in 64 for 64 once the count is large gave
+  // nothing for the 57 thousand given-up tiles of a palette batch: the additions wait while others search)
   const uint32_t k = atomicAdd(given_up, 1u);
   if (k < kFewTiles) given_up[kFewListAt + k] = tile;
 }
@@ -3120,7 +3122,8 @@ extern "C" int vp8l_encode_device_noalloc(int device, void *stream, const uint32
   return (int)(int64_t)host_result[0];
 }
 
-// Measurement aid: why k_lz77_dominant left tiles to the exhaustive kernel since the last call (then cleared); see g_dm_reason.
+// Measurement aid: why k_lz77_dominant left tiles to the exhaustive kernel since the last call (then cleared); see g_dm_reason
+// (zeros from a library that was not built with -DVP8L_PHASE_TIMING: the counting costs time).
 extern "C" int vp8l_debug_dominant_reasons(unsigned int *out4) {
   if (!out4) return VP8L_ERR_BAD_ARGUMENT;
   if (!hip_ok(hipDeviceSynchronize(), "sync")) return VP8L_ERR_HIP;

@@ -44,8 +44,15 @@ static_assert(kDmThreads * kDmSeg >= kDmMaxW, "segment pass covers the window");
 static_assert(kDmMaxW <= (1u << kSpPosBits), "window indices fit an entry");
 
 // Why k_lz77_dominant left tiles to the exhaustive kernel, counted since the last vp8l_debug_dominant_reasons() call:
-// [0] no frequent value, [1] too many run starts of other values, [2] too many bucket entries to look at, [3] too many pairs
+// [0] no frequent value, [1] too many run starts of other values, [2] too many bucket entries to look at, [3] too many pairs.
+// Counted by measurement builds only: additions to one address from every workgroup go one after another, about 12 ns each
+// (65 thousand rejected tiles of photo-like planes: 0.75 ms, all that the kernel took for them).
 __device__ unsigned int g_dm_reason[4];
+#ifdef VP8L_PHASE_TIMING
+#define DM_REASON(k) atomicAdd(&g_dm_reason[k], 1u)
+#else
+#define DM_REASON(k) do {} while (0)
+#endif
 
 // Per-phase cycle counts (a measurement build only, -DVP8L_PHASE_TIMING: thread 0 of every workgroup adds the cycles
 // between phase marks; read with vp8l_debug_dominant_phase_cycles)
@@ -140,7 +147,7 @@ __device__ __forceinline__ bool lz77_dominant_tile(DmShared &S, const DmGeo &G, 
       best = cand > best ? cand : best;
     }
     if ((best >> 6) < 6) {  // no value holds a tenth of the samples: the tile stays with the exhaustive kernel
-      if (tid == 0) atomicAdd(&g_dm_reason[0], 1u);
+      if (tid == 0) DM_REASON(0);
       return false;
     }
     v0 = (uint32_t)__shfl((int)smp, (int)(63u - (best & 63u)), 64);
@@ -185,7 +192,7 @@ __device__ __forceinline__ bool lz77_dominant_tile(DmShared &S, const DmGeo &G, 
       uint32_t starts = 0;
       for (uint32_t w = 0; w < kDmWaves; w++) starts += S.wsum2[w];
       if (starts > kDmMaxStarts) {  // (the same in every thread)
-        if (tid == 0) atomicAdd(&g_dm_reason[1], 1u);
+        if (tid == 0) DM_REASON(1);
         return false;
       }
       if (first_look) {
@@ -339,7 +346,7 @@ __device__ __forceinline__ bool lz77_dominant_tile(DmShared &S, const DmGeo &G, 
       for (uint32_t w = 0; w < kDmWaves; w++) { if (w < wave) at += S.wsum[w]; total += S.wsum[w]; }
       if (total > kDmMaxVisits) {  // (every thread sees the same total) too much to look at
         if (sub > kDmMinSub) { sub >>= 1; __syncthreads(); continue; }
-        if (tid == 0) atomicAdd(&g_dm_reason[2], 1u);
+        if (tid == 0) DM_REASON(2);
         return false;
       }
 #pragma unroll
@@ -396,7 +403,7 @@ __device__ __forceinline__ bool lz77_dominant_tile(DmShared &S, const DmGeo &G, 
       for (uint32_t w = 0; w < kDmWaves; w++) { if (w < wave) my_off += S.wsum2[w]; n_pairs += S.wsum2[w]; }
       if (n_pairs > kDmPool) {  // (the same in every thread)
         if (sub > kDmMinSub) { sub >>= 1; __syncthreads(); continue; }
-        if (tid == 0) atomicAdd(&g_dm_reason[3], 1u);
+        if (tid == 0) DM_REASON(3);
         return false;
       }
       uint32_t cq[3], sum = 0;
@@ -792,7 +799,7 @@ __device__ __forceinline__ bool lz77_grams_tile(GmShared &S, const DmGeo &G, uin
 // workgroup's next tile is on its way from memory, into registers, while the current one is searched.  A tile that is
 // searched here gets the flag kTileDoneDominant; one that is not (no frequent value, too many run starts or list
 // entries) keeps its flag and is the exhaustive kernel's.  `counter` starts at 0 (cleared with the flags).
-constexpr uint32_t kDmChunk = 16;
+constexpr uint32_t kDmChunk = 16, kDmChunkFirstLook = 4;
 // SEARCH(S, geo) searches one tile whose window is in S.px; the rest is the same for both kernels of this file.
 template <class Shared, class Search>
 __device__ __forceinline__ void dense_tiles(Shared &S, const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
@@ -800,6 +807,7 @@ __device__ __forceinline__ void dense_tiles(Shared &S, const EncImage *__restric
                                             const uint8_t *__restrict__ dense_tile, uint32_t *__restrict__ counter, uint32_t take_flag,
                                             const uint32_t *__restrict__ waiting_tiles, Search search) {
   __shared__ uint32_t s_chunk;
+  __shared__ uint8_t s_worth[64];  // first look: the chunk's tiles that have a frequent value
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   // waiting_tiles (may be null): an upper bound of the tiles with the flag, counted by the kernel that set it.  None: nothing
   // to do (a look at a million flags of a batch that needs none of this took 0.76 ms); few: the flags are looked at 64 at a time
@@ -807,8 +815,9 @@ __device__ __forceinline__ void dense_tiles(Shared &S, const EncImage *__restric
   if (n_waiting == 0) return;
   // many waiting: few tile numbers at a time, so that the last workgroups do not work on alone (one tile at a time when there are
   // hardly more tiles than workgroups); few waiting among many: 64 flags at a look
-  const uint32_t per_group = ntiles / (4 * gridDim.x);
-  const uint32_t chunk_tiles = (uint64_t)n_waiting * 8 > ntiles ? (per_group < 1 ? 1u : per_group > kDmChunk ? kDmChunk : per_group) : 64u;
+  // (a first look finds its tiles next to one another, 50 us each: in sixteens, the last workgroups worked on alone for 0.8 ms)
+  const uint32_t per_group = ntiles / (4 * gridDim.x), most_at_once = take_flag == 0 ? kDmChunkFirstLook : kDmChunk;
+  const uint32_t chunk_tiles = (uint64_t)n_waiting * 8 > ntiles ? (per_group < 1 ? 1u : per_group > most_at_once ? most_at_once : per_group) : 64u;
   uint32_t chunk = 0;
   uint64_t waiting = 0;  // tiles of the chunk that are still to do (the same in every thread)
   // the next waiting tile, or ~0u when the counter has run past the last tile; called by all threads
@@ -822,9 +831,32 @@ __device__ __forceinline__ void dense_tiles(Shared &S, const EncImage *__restric
       if (tid == 0) s_chunk = atomicAdd(counter, chunk_tiles);
       __syncthreads();
       chunk = s_chunk;
-      __syncthreads();  // everyone has read it before it is written again
+      // When this kernel looks first (every tile is a candidate), the tiles without a frequent value are told here, each from 64
+      // samples read straight from memory (the vote that the search begins with, on the same samples), the waves taking the
+      // chunk's tiles in turn: the tiles of photo-like predictor planes, three quarters of a mixed batch, cost a window, two
+      // barriers and - the most - the chain of loads to their geometry each, one tile after another.
+      if (take_flag == 0 && chunk < ntiles) {
+        for (uint32_t k = tid >> 6; k < chunk_tiles && chunk + k < ntiles; k += kDmThreads / 64) {
+          const DmGeo g = dm_geometry(imgs, st, sb_first, n, chunk + k);
+          uint32_t most = 64;
+          if (g.W) {
+            const uint32_t smp = pix[g.pos0 + g.lo + (2 * lane + 1) * g.W / 128];
+            most = 0;
+#pragma unroll
+            for (int j = 0; j < 64; j += 4) {
+              const uint32_t votes = (uint32_t)__popcll(__ballot((uint32_t)__builtin_amdgcn_readlane((int)smp, j) == smp));
+              most = votes > most ? votes : most;
+            }
+          }
+          if (lane == 0) {
+            s_worth[k] = most >= 6;
+            if (most < 6) DM_REASON(0);
+          }
+        }
+      }
+      __syncthreads();  // everyone has read s_chunk before it is written again
       if (chunk >= ntiles) return ~0u;
-      waiting = __ballot(lane < chunk_tiles && chunk + lane < ntiles && dense_tile[chunk + lane] == take_flag);
+      waiting = __ballot(lane < chunk_tiles && chunk + lane < ntiles && dense_tile[chunk + lane] == take_flag && (take_flag != 0 || s_worth[lane]));
     }
   };
   uint4 ahead[kDmLoads];
