@@ -50,3 +50,12 @@ for it in range(2):
     stt = dec.decode_device(*args)
 assert (stt == 0).all() and torch.equal(d_dec, d_in)
 print("  decode: %.1f MP/s (device time %.1f ms, %d streams by the whole device)" % (mp / dec.last_device_seconds(), 1e3 * dec.last_device_seconds(), dec.last_whole_device_streams()))
+L = webp_amd.lib()
+if hasattr(L, "vp8l_debug_phase_cycles"):  # the measurement build: cycles between the phase marks of the candidate-list kernels
+    import ctypes as C
+    buf = (C.c_ulonglong * 8)()
+    L.vp8l_debug_phase_cycles(buf)
+    enc.encode_device(ptrs, [w] * batch, [h] * batch, d_out.data_ptr(), d_out.numel())
+    L.vp8l_debug_phase_cycles(buf)
+    tot = float(sum(buf)) or 1.0
+    print("  phase shares: " + "  ".join("%d: %.3f" % (k, buf[k] / tot) for k in range(8)))

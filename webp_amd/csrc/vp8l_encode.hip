@@ -52,8 +52,14 @@ template <class Slot>
 __device__ __forceinline__ int set_insert(Slot *set, uint32_t v) {
   uint32_t h = hash_px(v);
   for (uint32_t probe = 0; probe < kSetSlots; probe++) {
-    const unsigned long long old = atomicCAS((unsigned long long *)&set[h], (unsigned long long)kEmptySlot, (unsigned long long)v);
-    if (old == kEmptySlot) return 1;
+    // A look first: a slot that holds a colour keeps it, so what is seen there holds, and the lanes of a wave that ask for one
+    // colour of a small palette read one address at once instead of queueing for it (a slot seen empty is then claimed, or
+    // found taken, by the compare-and-swap).
+    unsigned long long old = *(volatile Slot *)&set[h];
+    if (old == kEmptySlot) {
+      old = atomicCAS((unsigned long long *)&set[h], (unsigned long long)kEmptySlot, (unsigned long long)v);
+      if (old == kEmptySlot) return 1;
+    }
     if ((uint32_t)old == v) return 0;
     h = (h + 1) & (kSetSlots - 1);
   }
@@ -101,19 +107,50 @@ __global__ __launch_bounds__(256) void k_palette_scan(const EncImage *__restrict
   for (uint32_t i = tid; i < kSetSlots; i += 256) set[i] = kEmptySlot;
   if (tid == 0) { s_count = 0; s_over = 0; }
   __syncthreads();
-  for (uint32_t it = 0; it < kSuper / 256; it++) {
-    const uint64_t i = base + (uint64_t)it * 256 + tid;
-    {
-      // a pixel equal to the one before it (the lane below) adds nothing: flat areas cost one insertion per run and wave
-      const uint32_t v = i < npx ? im.argb[i] : 0u;
-      const uint32_t left = (uint32_t)__shfl_up((int)v, 1, 64);
-      if (i < npx && ((tid & 63) == 0 || v != left)) {
-        const int r = set_insert(set, v);
-        if (r == 1) atomicAdd(&s_count, 1u);
-        if (r == 2) s_over = 1;
+  // A round is kScanRows rows of 1024 pixels, four neighbours per thread and row (one 16-byte load where the caller's pixels
+  // are aligned so): enough bytes on their way per thread to keep the memory busy, and the next round's are loaded while this
+  // round's are looked up.  A round ends with the look at the count (a round may bring more colours than the set holds: then the
+  // set says so, and the count is past 256 as well).
+  constexpr uint32_t kScanRows = 2, kRound = 1024 * kScanRows;
+  const bool aligned = (reinterpret_cast<uintptr_t>(im.argb) & 15) == 0;
+  auto load4 = [&](uint64_t i) -> uint4 {
+    if (aligned && i + 4 <= npx) return *reinterpret_cast<const uint4 *>(im.argb + i);
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (i < npx) q.x = im.argb[i];
+    if (i + 1 < npx) q.y = im.argb[i + 1];
+    if (i + 2 < npx) q.z = im.argb[i + 2];
+    if (i + 3 < npx) q.w = im.argb[i + 3];
+    return q;
+  };
+  uint4 ahead[kScanRows];
+#pragma unroll
+  for (uint32_t j = 0; j < kScanRows; j++) ahead[j] = load4(base + j * 1024 + tid * 4);
+  for (uint32_t it = 0; it < kSuper / kRound; it++) {
+    const uint64_t i0 = base + (uint64_t)it * kRound + tid * 4;
+    uint4 v[kScanRows];
+#pragma unroll
+    for (uint32_t j = 0; j < kScanRows; j++) v[j] = ahead[j];
+    if (it + 1 < kSuper / kRound) {
+#pragma unroll
+      for (uint32_t j = 0; j < kScanRows; j++) ahead[j] = load4(i0 + kRound + j * 1024);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kScanRows; j++) {
+      // a pixel equal to the one before it adds nothing: flat areas cost one insertion per run and wave
+      const uint64_t i = i0 + j * 1024;
+      const uint32_t four[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+      const uint32_t left = (uint32_t)__shfl_up((int)four[3], 1, 64);
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) {
+        const bool fresh = q ? four[q] != four[q - 1] : ((tid & 63) == 0 || four[0] != left);
+        if (i + q < npx && fresh) {
+          const int r = set_insert(set, four[q]);
+          if (r == 1) atomicAdd(&s_count, 1u);
+          if (r == 2) s_over = 1;
+        }
       }
     }
-    if (tid == 0 && (it & 7) == 7 &&
+    if (tid == 0 && (it & 1) == 1 &&
         __hip_atomic_load(&st[img].pal_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       s_over = 1;
     __syncthreads();
@@ -124,7 +161,7 @@ __global__ __launch_bounds__(256) void k_palette_scan(const EncImage *__restrict
       if (tid == 0 && too_many) __hip_atomic_store(&st[img].pal_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
-    if (base + (uint64_t)(it + 1) * 256 >= npx) break;
+    if (base + (uint64_t)(it + 1) * kRound >= npx) break;
   }
   unsigned long long *gset = gsets + (size_t)img * kSetSlots;
   for (uint32_t s = tid; s < kSetSlots; s += 256) {
@@ -212,12 +249,49 @@ __global__ __launch_bounds__(256) void k_palette_finalize(const EncImage *__rest
 // Forward transform: one coded pixel per thread-iteration, 8 B of HBM traffic per pixel on the
 // subtract-green path, 4 + 4/2^bits on the colour-indexing path.
 // =============================================================================================
+// Colour indexing of one superblock of coded pixels, 2^BITS pixels to a coded one (vp8l.h:438-443, 598-611).  A few coded pixels
+// per thread at a time, all their pixels loaded before the first is looked up (clamped addresses, so that no load waits for a
+// test): one pixel after the other, the kernel waited for memory 64 times per thread.
+template <uint32_t BITS>
+__device__ __forceinline__ void index_superblock(const uint32_t *__restrict__ argb, uint32_t w, uint32_t xsize, uint32_t M, uint32_t p0,
+                                                 uint32_t tid, const unsigned long long *pal_index, uint32_t *__restrict__ dst) {
+  constexpr uint32_t kPer = 1u << BITS, kDepth = 8u >> BITS, kAtOnce = kPer >= 4 ? 2 : 4;
+#pragma unroll 1
+  for (uint32_t k = 0; k < kSuper / 256 && p0 + k * 256 < M; k += kAtOnce) {
+    uint32_t v[kAtOnce][kPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kAtOnce; u++) {
+      const uint32_t p = p0 + (k + u) * 256 + tid, pc = p < M ? p : M - 1;
+      const uint32_t y = pc / xsize, x0 = (pc - y * xsize) << BITS;
+#pragma unroll
+      for (uint32_t j = 0; j < kPer; j++) v[u][j] = argb[(uint64_t)y * w + (x0 + j < w ? x0 + j : w - 1)];  // (past the row's end: not used)
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kAtOnce; u++) {
+      const uint32_t p = p0 + (k + u) * 256 + tid, pc = p < M ? p : M - 1;
+      const uint32_t x0 = (pc % xsize) << BITS;
+      uint32_t code = 0xff000000u;
+#pragma unroll
+      for (uint32_t j = 0; j < kPer; j++) {
+        uint32_t h = hash_px(v[u][j]);
+        unsigned long long e = pal_index[h];
+        for (uint32_t probe = 0; (uint32_t)e != v[u][j] && probe < kSetSlots; probe++) {  // (every pixel's colour is in the palette)
+          h = (h + 1) & (kSetSlots - 1);
+          e = pal_index[h];
+        }
+        if (x0 + j < w) code |= (uint32_t)(e >> 32) << (8 + kDepth * j);
+      }
+      if (p < M) dst[p] = code;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_transform(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                    const uint32_t *__restrict__ sb_first, uint32_t n,
                                                    uint32_t *__restrict__ pix) {
   // a superblock per workgroup: most calls have nothing for this kernel to do (the match kernel makes the residual of
   // aligned non-palette images itself), and workgroups that only look and leave cost what their launch costs
-  __shared__ uint32_t pal[kMaxPalette];
+  __shared__ unsigned long long pal_index[kSetSlots];  // index << 32 | colour
   const uint32_t sb = blockIdx.x, img = find_image(sb_first, n, sb), tid = threadIdx.x;
   const EncImage im = imgs[img];
   const uint32_t M = st[img].M, ncolors = st[img].ncolors;
@@ -232,23 +306,22 @@ __global__ __launch_bounds__(256) void k_transform(const EncImage *__restrict__ 
     }
     return;
   }
-  if (tid < ncolors) pal[tid] = st[img].palette[tid];
+  // index of a colour in the sorted palette (vp8l.h:438-443; the colours are distinct): from a table on the colour's hash, one or
+  // two reads instead of the eight dependent ones of a search through 256 colours
+  for (uint32_t i = tid; i < kSetSlots; i += 256) pal_index[i] = kEmptySlot;
   __syncthreads();
-  const uint32_t bits = st[img].bits, xsize = st[img].xsize, depth = 8u >> bits, per = 1u << bits;
-  for (uint32_t k = 0; k < kSuper / 256; k++) {
-    const uint32_t p = p0 + k * 256 + tid;
-    if (p >= M) break;
-    const uint32_t y = p / xsize, xp = p - y * xsize;
-    uint32_t code = 0xff000000u;
-    for (uint32_t j = 0; j < per; j++) {
-      const uint32_t x = (xp << bits) + j;
-      if (x >= im.w) break;
-      const uint32_t v = im.argb[(uint64_t)y * im.w + x];
-      uint32_t lo = 0, hi = ncolors;  // index of v in the sorted palette = the first equal entry (vp8l.h:438-443)
-      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pal[mid] < v) lo = mid + 1; else hi = mid; }
-      code |= lo << (8 + depth * j);
-    }
-    dst[p] = code;
+  if (tid < ncolors) {
+    const uint32_t v = st[img].palette[tid];
+    uint32_t h = hash_px(v);
+    while (atomicCAS(&pal_index[h], (unsigned long long)kEmptySlot, ((unsigned long long)tid << 32) | v) != kEmptySlot) h = (h + 1) & (kSetSlots - 1);
+  }
+  __syncthreads();
+  const uint32_t xsize = st[img].xsize;
+  switch (st[img].bits) {
+    case 0: index_superblock<0>(im.argb, im.w, xsize, M, p0, tid, pal_index, dst); break;
+    case 1: index_superblock<1>(im.argb, im.w, xsize, M, p0, tid, pal_index, dst); break;
+    case 2: index_superblock<2>(im.argb, im.w, xsize, M, p0, tid, pal_index, dst); break;
+    default: index_superblock<3>(im.argb, im.w, xsize, M, p0, tid, pal_index, dst); break;
   }
 }
 
@@ -1184,10 +1257,14 @@ __device__ __forceinline__ void lz77_sparse_tile(const EncImage *__restrict__ im
       // Pairs of pixels hardly repeat: the table on pairs finds every match of two pixels and more with short walks,
       // and only the positions that have none walk the table on single pixels afterwards, 64 to a round.
       build_grouped(std::true_type{});
+      VP8L_PHASE_MARK(4);  // (tiles of k_lz77_pairs: 4 the table on pairs, 5 its walks and scores, 6 the table on pixels, 7 its walks)
       const bool gave_up = collect_and_score(aux + wave * kSpWaveAux, std::true_type{}, std::true_type{}, open_positions);
       __syncthreads();  // every wave is done with the table on pairs
+      VP8L_PHASE_MARK(5);
       build_grouped(std::false_type{});
+      VP8L_PHASE_MARK(6);
       if (!gave_up) farthest_of_value(reinterpret_cast<uint16_t *>(aux + wave * kSpWaveAux), open_positions);
+      VP8L_PHASE_MARK(7);
       return;
      }
     }
