@@ -196,3 +196,32 @@ def test_pixels_not_16_byte_aligned():
         assert bytes(d_out[int(off[0]): int(off[0]) + int(lens[0])].cpu().numpy()) == ref, shift
         assert np.array_equal(enc.fetch_stage(0, webp_amd.STAGE_RESIDUAL), O.encode(img, w, h, trace=True)[2]["residual"])
     enc.close()
+
+
+def test_palette_scan_edges():
+    # The palette scan reads 16 bytes a thread where the caller's pixels are aligned so and falls back to single words
+    # at the end of an image and for unaligned pointers; colours that show only in the last pixels, in the last partial
+    # group of four, or first beyond 256 must be seen all the same.  Images of several 16384-pixel superblocks.
+    torch = torch_cuda()
+    rng = np.random.default_rng(2026)
+    enc = webp_amd.Encoder()
+    cases = []
+    for (w, h, ncol) in ((201, 199, 16), (130, 127, 256), (257, 130, 3), (181, 183, 200)):
+        pal = rng.choice(1 << 32, size=ncol + 2, replace=False).astype(np.uint32)
+        base = pal[rng.integers(0, max(1, ncol - 1), size=w * h)]
+        a = base.copy(); a[-1] = pal[ncol - 1]                     # the last colour of the palette only in the last pixel
+        b = a.copy(); b[-2] = pal[ncol]; b[-3] = pal[ncol + 1]     # two more at the very end (beyond 256 for ncol = 256)
+        c = base.copy(); c[16384 + 5] = pal[ncol - 1]              # ... or once in the second superblock
+        cases += [(a, w, h), (b, w, h), (c, w, h)]
+    for img, w, h in cases:
+        rc, ref = O.encode(img, w, h)
+        assert rc == 0
+        cap = enc.bound(w, h)
+        d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        for shift in (0, 1, 3):
+            buf = torch.zeros(w * h + 8, dtype=torch.int32, device="cuda")
+            buf[shift: shift + w * h] = torch.from_numpy(img.view(np.int32)).cuda()
+            off, lens, status = enc.encode_device([buf.data_ptr() + 4 * shift], [w], [h], d_out.data_ptr(), cap)
+            assert status[0] == 0
+            assert bytes(d_out[int(off[0]): int(off[0]) + int(lens[0])].cpu().numpy()) == ref, (w, h, shift)
+    enc.close()
