@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256) void k_transform(const EncImage *__restrict__ 
   const uint32_t M = st[img].M, ncolors = st[img].ncolors;
   const uint32_t p0 = (sb - sb_first[img]) * kSuper;
   if (p0 >= M || st[img].fused) return;
+  if (ncolors == 0 && st[img].pred_bits) return;  // the predictor's kernels read the caller's pixels and subtract green themselves
   uint32_t *dst = pix + im.pos0;
   if (ncolors == 0) {
 #pragma unroll 4
@@ -517,24 +518,26 @@ __device__ __forceinline__ void lz77_tile(const uint32_t *__restrict__ data, uin
 // 0xff000000, the first row predicts L, the first column T, and TR of the last column is L.
 // =============================================================================================
 __device__ __forceinline__ uint32_t abs_cost(uint32_t r) {  // rough bit cost of the four residual bytes
-  uint32_t c = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const uint32_t b = (r >> (8 * k)) & 0xff, a = b < 128 ? b : 256 - b;  // |byte| as a signed value
-    c += a ? 1u + 2u * (32u - (uint32_t)__clz((int)a)) : 0u;               // nothing for zero, else 1 + 2 * bits of |v|
-  }
-  return c;
+  // Per byte, taken as a signed value v: nothing for zero, else 1 + 2 * (bits of |v|).  All four bytes at once (this is most of
+  // what the choice of a tile's mode costs, 14 times a sample): |v| per byte, its bits smeared to the right so that a byte
+  // holds as many ones as |v| has bits, and then the sum over the bytes is a population count.
+  const uint32_t neg = (r >> 7) & 0x01010101u;
+  uint32_t a = (r ^ (neg * 0xffu)) + neg;  // 256 - b where b >= 128 (no byte carries: at most 0x7f + 1)
+  a |= (a >> 1) & 0x7f7f7f7fu;
+  a |= (a >> 2) & 0x3f3f3f3fu;
+  a |= (a >> 4) & 0x0f0f0f0fu;
+  return (uint32_t)__popc(a & 0x01010101u) + 2u * (uint32_t)__popc(a);
 }
 
 __global__ __launch_bounds__(256) void k_pred_modes(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
-                                                    const uint32_t *__restrict__ pix, uint32_t *__restrict__ modes, uint32_t standard) {
+                                                    uint32_t *__restrict__ modes, uint32_t standard) {
   __shared__ uint32_t wcost[4][14];
   const uint32_t img = blockIdx.x / kSmallMax, tile = blockIdx.x % kSmallMax, tid = threadIdx.x;
   const EncState &s = st[img];
   const uint32_t bits = s.pred_bits;
   if (bits == 0 || s.ncolors || tile >= s.pred_tx * s.pred_ty) return;
   const uint32_t w = imgs[img].w, h = imgs[img].h;
-  const uint32_t *src = pix + imgs[img].pos0;
+  const uint32_t *src = imgs[img].argb;  // green is subtracted on the way in: k_transform leaves predictor images alone
   const uint32_t tx = tile % s.pred_tx, ty = tile / s.pred_tx, side = 1u << bits;
   const uint32_t x0 = tx << bits, y0 = ty << bits;
   uint32_t cost[14];
@@ -545,8 +548,8 @@ __global__ __launch_bounds__(256) void k_pred_modes(const EncImage *__restrict__
     const uint32_t x = x0 + 2 * (k % half) + 1, y = y0 + 2 * (k / half) + 1;  // odd offsets: never the first row or column
     if (x >= w || y >= h) continue;
     const uint64_t i = (uint64_t)y * w + x;
-    const uint32_t cur = src[i], L = src[i - 1], T = src[i - w], TL = src[i - w - 1];
-    const uint32_t TR = x == w - 1 && !standard ? L : src[i - w + 1];  // standard dialect: the next pixel in memory (first of the current row)
+    const uint32_t cur = subtract_green(src[i]), L = subtract_green(src[i - 1]), T = subtract_green(src[i - w]), TL = subtract_green(src[i - w - 1]);
+    const uint32_t TR = x == w - 1 && !standard ? L : subtract_green(src[i - w + 1]);  // standard dialect: the next pixel in memory (first of the current row)
 #pragma unroll
     for (int m = 0; m < 14; m++) cost[m] += abs_cost(px_sub(cur, predict((uint32_t)m, L, T, TR, TL)));
   }
@@ -566,7 +569,8 @@ __global__ __launch_bounds__(256) void k_pred_modes(const EncImage *__restrict__
   }
 }
 
-// dst = residual (predictor images) or a copy (all others), so that later stages read one array
+// dst = residual (predictor images, made from the caller's pixels: green is subtracted on the way in) or a copy of the
+// transformed pixels (all others), so that later stages read one array
 __global__ __launch_bounds__(256) void k_pred_residual(const EncImage *__restrict__ imgs, const EncState *__restrict__ st,
                                                        const uint32_t *__restrict__ sb_first, uint32_t n,
                                                        const uint32_t *__restrict__ pix, const uint32_t *__restrict__ modes,
@@ -577,25 +581,68 @@ __global__ __launch_bounds__(256) void k_pred_residual(const EncImage *__restric
   const uint32_t p0 = (unit - sb_first[img] * kUnitsPerSuper) * kUnit;
   if (p0 >= M) return;
   const uint64_t pos0 = imgs[img].pos0;
-  const uint32_t *src = pix + pos0;
   uint32_t *out = dst + pos0;
   const uint32_t bits = s.ncolors ? 0u : s.pred_bits, w = imgs[img].w;
-  const uint32_t *mimg = modes + (size_t)img * kSmallMax;
-  for (uint32_t k = 0; k < kUnit / 256; k++) {
-    const uint32_t p = p0 + k * 256 + tid;
-    if (p >= M) break;
-    const uint32_t cur = src[p];
-    if (bits == 0) { out[p] = cur; continue; }
-    const uint32_t y = p / w, x = p - y * w;
-    uint32_t P;
-    if (y == 0) P = x == 0 ? 0xff000000u : src[p - 1];
-    else if (x == 0) P = src[p - w];
-    else {
-      const uint32_t L = src[p - 1];
-      const uint32_t mode = (mimg[(y >> bits) * s.pred_tx + (x >> bits)] >> 8) & 0xff;
-      P = predict(mode, L, src[p - w], x == w - 1 && !standard ? L : src[p - w + 1], src[p - w - 1]);
+  if (bits == 0) {
+    const uint32_t *src = pix + pos0;
+    for (uint32_t k = 0; k < kUnit / 256; k++) {
+      const uint32_t p = p0 + k * 256 + tid;
+      if (p < M) out[p] = src[p];
     }
-    out[p] = px_sub(cur, P);
+    return;
+  }
+  const uint32_t *src = imgs[img].argb;
+  const uint32_t *mimg = modes + (size_t)img * kSmallMax;
+  const uint32_t tiles_x = s.pred_tx;
+  auto mode_at = [&](uint32_t x, uint32_t y) { return (mimg[(y >> bits) * tiles_x + (x >> bits)] >> 8) & 0xff; };
+  // one pixel, whatever its place (transform.h:110-191: (0,0) predicts 0xff000000, the first row L, the first column T)
+  auto one = [&](uint32_t p, uint32_t x, uint32_t y) -> uint32_t {
+    const uint32_t cur = subtract_green(src[p]);
+    uint32_t P;
+    if (y == 0) P = x == 0 ? 0xff000000u : subtract_green(src[p - 1]);
+    else if (x == 0) P = subtract_green(src[p - w]);
+    else {
+      const uint32_t L = subtract_green(src[p - 1]);
+      P = predict(mode_at(x, y), L, subtract_green(src[p - w]), x == w - 1 && !standard ? L : subtract_green(src[p - w + 1]), subtract_green(src[p - w - 1]));
+    }
+    return px_sub(cur, P);
+  };
+  // Four neighbouring pixels a thread: inside a row (not its first or last pixels, not the first row) they share their
+  // neighbours, 11 pixels read and turned instead of 20, and are stored as one 16-byte word (the region is aligned so).
+  // Row and column are divided out once per thread, then moved on by 1024 pixels a step.
+  uint32_t y = (p0 + tid * 4) / w, x = (p0 + tid * 4) - y * w;
+  for (uint32_t k = 0; k < kUnit / 1024; k++) {
+    const uint32_t p = p0 + k * 1024 + tid * 4;
+    if (p >= M) break;
+    uint32_t r[4];
+    if (y > 0 && x > 0 && x + 4 < w && p + 4 <= M) {
+      uint32_t c[5], t[6];  // c[0] = L, c[1..4] the pixels; t[0] = TL of the first, t[1..4] above the pixels, t[5] = TR of the last
+#pragma unroll
+      for (int j = 0; j < 5; j++) c[j] = subtract_green(src[p - 1 + j]);
+#pragma unroll
+      for (int j = 0; j < 6; j++) t[j] = subtract_green(src[p - w - 1 + j]);
+      const uint32_t m_first = mode_at(x, y), m_last = mode_at(x + 3, y);
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t mode = ((x + j) >> bits) == (x >> bits) ? m_first : m_last;
+        r[j] = px_sub(c[j + 1], predict(mode, c[j], t[j + 1], t[j + 2], t[j]));
+      }
+    } else {
+      uint32_t xx = x, yy = y;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        r[j] = p + j < M ? one(p + j, xx, yy) : 0u;
+        if (++xx == w) { xx = 0; yy++; }
+      }
+    }
+    *reinterpret_cast<uint4 *>(out + p) = make_uint4(r[0], r[1], r[2], r[3]);  // (the region has slack past M)
+    x += 1024;
+    if (w >= 1024) {
+      if (x >= w) { x -= w; y++; }
+    } else {
+      y += x / w;
+      x %= w;
+    }
   }
 }
 
@@ -2605,7 +2652,7 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
   mark(1);
   hipLaunchKernelGGL(k_transform, dim3(gsb), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix_t);
   if (pred) {
-    hipLaunchKernelGGL(k_pred_modes, dim3(nl * kSmallMax), dim3(256), 0, s, B.imgs, B.st, B.pix_t, B.modes, standard);
+    hipLaunchKernelGGL(k_pred_modes, dim3(nl * kSmallMax), dim3(256), 0, s, B.imgs, B.st, B.modes, standard);
     hipLaunchKernelGGL(k_pred_residual, dim3(gunits), dim3(256), 0, s, B.imgs, B.st, B.sbf, nl, B.pix_t, B.modes, B.pix, standard);
   }
   if (cross) {  // on what the predictor left (in place), or on the subtract-green image
