@@ -49,7 +49,7 @@ def stage_bytes_per_pixel(bpp, palette_share=0.0, predictor=False):
     palette images (only those are scanned to the end and go through k_transform; the others leave the palette scan after a
     few hundred pixels per block and get their residual from the match kernel).  predictor: the predictor transform runs."""
     if predictor:
-        transform = 8.0 + 4.0 + 8.0       # subtract green (4 + 4), mode choice (4 read), residual (4 + 4)
+        transform = 1.0 + 8.0             # mode choice (every fourth pixel is a sample; green subtracted on the way in), residual (4 + 4)
     else:
         transform = 8.0 * palette_share   # indices: 4 read, at most 4 written
     return {
