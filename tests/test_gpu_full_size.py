@@ -124,3 +124,27 @@ def test_single_16383x16383_image_against_the_oracles_known_answer(case):   # co
     assert modes is not None and modes["tx"] * modes["ty"] <= 1024 and (modes["tx"] << modes["bits"]) >= w
     assert int(lens[0]) < case["bytes"]          # the predictor pays on both generators
     assert torch.equal(decode(torch, d_out, off, lens, w, h), d_in)
+
+
+def test_chain_walk_of_an_image_of_many_superblocks_against_the_oracle():
+    """An image of more than 1024 superblocks of 16384 positions has its parse's chain walked by a workgroup per round of 128
+    superblocks (two launches) instead of one workgroup per image; any walk gives a stream that decodes, only the right
+    one gives the oracle's bytes.  In one call with a small image, so that the rounds of two images lie side by side."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _oracle as O
+    sizes = [(4200, 4100), (640, 480)]
+    imgs = [O.gen_image(4, w, h, 31 + k, 200) for k, (w, h) in enumerate(sizes)]
+    d_in = [torch.from_numpy(a.view(np.int32)).cuda() for a in imgs]
+    enc = webp_amd.Encoder()
+    caps = [enc.bound(w, h) for w, h in sizes]
+    d_out = torch.empty(sum(caps), dtype=torch.uint8, device="cuda")
+    off, lens, st = enc.encode_device([d.data_ptr() for d in d_in], [w for w, _ in sizes], [h for _, h in sizes], d_out.data_ptr(), d_out.numel())
+    enc.close()
+    assert (st == 0).all()
+    for k, (w, h) in enumerate(sizes):
+        rc, ref = O.encode(imgs[k], w, h)
+        assert rc == 0
+        assert bytes(d_out[int(off[k]): int(off[k]) + int(lens[k])].cpu().numpy()) == ref, (w, h)

@@ -1618,6 +1618,84 @@ __global__ __launch_bounds__(256) void k_parse_chain(const EncState *__restrict_
   }
 }
 
+// The same for images of many superblocks (one 16383 x 16383 image has 16382: the kernel above walks them in 128 rounds, one
+// after another, 0.4 ms of the image's 4.4), in two launches with a workgroup per round of 128 tables:
+//   k_parse_chain_maps     composes the round's tables into one, the round's exit for each of the 128 entries (rmap);
+//   k_parse_chain_entries  takes entry 0 through the maps of the rounds before its own (at most 127 lookups out of LDS), then
+//                          through its own round as the kernel above does, and writes the entries of its superblocks.
+// rmap: scratch of 128 bytes per round; the rounds of image i start at round sb_first[i] / 128 + i (no two images share one).
+constexpr uint32_t kChainRound = 128, kChainGroup = 8, kChainGroups = kChainRound / kChainGroup;
+constexpr uint32_t kChainMaxRounds = 128;  // (16384 superblocks: the largest image, 16384 x 16384, has as many)
+constexpr uint32_t kChainSerialMax = 1024; // images up to so many superblocks (8 rounds) are walked by k_parse_chain, one workgroup each
+// loads the tables of round r of an image (cnt of them) into tab and composes every group of 8 into gmap; ends with a barrier
+__device__ __forceinline__ void chain_round_tables(const uint8_t *__restrict__ sx, uint32_t sb, uint32_t cnt, uint8_t *tab, uint8_t *gmap, uint32_t tid) {
+  const uint4 *src = reinterpret_cast<const uint4 *>(sx + (size_t)sb * kBlockLen);
+  for (uint32_t i = tid; i < kChainRound * kBlockLen / 16; i += 256)
+    reinterpret_cast<uint4 *>(tab)[i] = i < cnt * kBlockLen / 16 ? src[i] : make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  for (uint32_t k = tid; k < kChainGroups * kBlockLen; k += 256) {
+    const uint32_t grp = k / kBlockLen;
+    uint32_t x = k % kBlockLen;
+    for (uint32_t j = 0; j < kChainGroup && grp * kChainGroup + j < cnt; j++) x = tab[(grp * kChainGroup + j) * kBlockLen + x];
+    gmap[k] = (uint8_t)x;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_parse_chain_maps(const EncState *__restrict__ st, const uint32_t *__restrict__ sb_first,
+                                                          const uint8_t *__restrict__ sx, uint8_t *__restrict__ rmap) {
+  __shared__ __attribute__((aligned(16))) uint8_t tab[kChainRound * kBlockLen];
+  __shared__ uint8_t gmap[kChainGroups * kBlockLen];
+  const uint32_t img = blockIdx.y, r = blockIdx.x, tid = threadIdx.x;
+  const uint32_t nsb = (st[img].M + kSuper - 1) / kSuper, sb0 = sb_first[img];
+  if (r * kChainRound >= nsb) return;
+  const uint32_t cnt = nsb - r * kChainRound < kChainRound ? nsb - r * kChainRound : kChainRound;
+  chain_round_tables(sx, sb0 + r * kChainRound, cnt, tab, gmap, tid);
+  if (tid < kBlockLen) {
+    uint32_t x = tid;
+    for (uint32_t grp = 0; grp < kChainGroups; grp++) x = gmap[grp * kBlockLen + x];  // (groups past cnt map every entry to itself)
+    rmap[((size_t)(sb0 / kChainRound + img) + r) * kBlockLen + tid] = (uint8_t)x;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_parse_chain_entries(const EncState *__restrict__ st, const uint32_t *__restrict__ sb_first,
+                                                             const uint8_t *__restrict__ sx, const uint8_t *__restrict__ rmap,
+                                                             uint8_t *__restrict__ entry) {
+  __shared__ __attribute__((aligned(16))) uint8_t tab[kChainRound * kBlockLen];  // first the maps of the rounds before, then the round's tables
+  __shared__ uint8_t gmap[kChainGroups * kBlockLen];
+  __shared__ uint8_t gent[kChainGroups];
+  __shared__ uint32_t s_e;
+  const uint32_t img = blockIdx.y, r = blockIdx.x, tid = threadIdx.x;
+  const uint32_t nsb = (st[img].M + kSuper - 1) / kSuper, sb0 = sb_first[img];
+  if (r * kChainRound >= nsb) return;
+  if (r >= kChainMaxRounds) return;  // (the launch takes this form only where the maps of an image fit tab)
+  const uint32_t cnt = nsb - r * kChainRound < kChainRound ? nsb - r * kChainRound : kChainRound;
+  const uint4 *maps = reinterpret_cast<const uint4 *>(rmap + (size_t)(sb0 / kChainRound + img) * kBlockLen);
+  for (uint32_t i = tid; i < r * kBlockLen / 16; i += 256) reinterpret_cast<uint4 *>(tab)[i] = maps[i];
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t x = 0;  // the chain enters an image at its first position
+    for (uint32_t k = 0; k < r; k++) x = tab[k * kBlockLen + x];
+    s_e = x;
+  }
+  __syncthreads();
+  const uint32_t e = s_e;
+  __syncthreads();
+  chain_round_tables(sx, sb0 + r * kChainRound, cnt, tab, gmap, tid);
+  if (tid == 0) {
+    uint32_t x = e;
+    for (uint32_t grp = 0; grp < kChainGroups; grp++) { gent[grp] = (uint8_t)x; x = gmap[grp * kBlockLen + x]; }
+  }
+  __syncthreads();
+  if (tid < kChainGroups) {
+    uint32_t x = gent[tid];
+    for (uint32_t j = 0; j < kChainGroup && tid * kChainGroup + j < cnt; j++) {
+      entry[sb0 + r * kChainRound + tid * kChainGroup + j] = (uint8_t)x;
+      x = tab[(tid * kChainGroup + j) * kBlockLen + x];
+    }
+  }
+}
+
 // Marks the token starts of a superblock and, in the same kernel, counts their symbols (vp8l.h:516-535): the walks above are
 // chains of dependent LDS reads that leave the memory system idle, the histogram is loads and LDS atomics, so the workgroups of
 // one CU overlap the two.  The histogram takes over the LDS of the advances once the marks are made.
@@ -2631,7 +2709,8 @@ struct EncBuffers {
 // superblocks; imgs and sbf are already on their way on the same stream.  ev: ten events for stage times, or null.
 static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl, uint32_t sb_total, uint32_t pred, uint32_t cross,
                                  int match_mode, uint8_t *d_out, hipEvent_t *ev, uint32_t standard = 0, const ExtArgs *extp = nullptr,
-                                 uint32_t meta_bits = 0) {
+                                 uint32_t meta_bits = 0, uint32_t max_sb_per_image = 0) {
+  // max_sb_per_image: the most superblocks any image of the call has (0: not known; picks the form of the parse's chain walk)
   // match_mode 2: the candidate lists refuse every tile (no bucket may hold anything), so that the forms behind them see all tiles
   const uint32_t tune_max_bucket = (match_mode == 2 || match_mode == 3) ? 0u : g_tune[2];
   const bool with_grams = match_mode == 3 || (g_tune[3] & 2u);
@@ -2703,7 +2782,15 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
                      match_mode == 0 ? B.dense : (const uint8_t *)nullptr);
   mark(3);
   hipLaunchKernelGGL(k_parse_exits, dim3(gsb), dim3(128), 0, s, B.imgs, B.st, B.sbf, nl, B.adv8, B.sx);
-  hipLaunchKernelGGL(k_parse_chain, dim3(nl), dim3(256), 0, s, B.st, B.sbf, B.sx, B.entry);
+  if (max_sb_per_image > kChainSerialMax && max_sb_per_image <= kChainMaxRounds * kChainRound) {
+    // the maps of the rounds lie where the token-start bits will be (k_parse_mark writes those after this, every word of them)
+    uint8_t *rmap = reinterpret_cast<uint8_t *>(B.flags);
+    const dim3 grid((max_sb_per_image + kChainRound - 1) / kChainRound, nl);
+    hipLaunchKernelGGL(k_parse_chain_maps, grid, dim3(256), 0, s, B.st, B.sbf, B.sx, rmap);
+    hipLaunchKernelGGL(k_parse_chain_entries, grid, dim3(256), 0, s, B.st, B.sbf, B.sx, (const uint8_t *)rmap, B.entry);
+  } else {
+    hipLaunchKernelGGL(k_parse_chain, dim3(nl), dim3(256), 0, s, B.st, B.sbf, B.sx, B.entry);
+  }
   const bool ext_on = extp && extp->on;
   // the units' bit sums from the symbol counts of the units (k_unit_bits) instead of a pass over pixels and matches (k_bitcount);
   // VP8L_TUNE's fourth value, bit 3: the pass
@@ -2818,6 +2905,7 @@ static int vp8l_encoder_encode_device_impl(vp8l_encoder *e, size_t n, const uint
   }
   const uint32_t nl = (uint32_t)live.size();
   if (nl == 0) return VP8L_OK;
+  uint64_t max_sb = 0;
   for (uint32_t k = 0; k < nl; k++) {
     const size_t i = live[k];
     const uint64_t px = (uint64_t)width[i] * height[i];
@@ -2830,6 +2918,7 @@ static int vp8l_encoder_encode_device_impl(vp8l_encoder *e, size_t n, const uint
     im.out_cap = vp8l_encode_bound(width[i], height[i]);
     e->sb_first[k] = (uint32_t)sb_total;
     sb_total += (px + kTailPad + kSuper - 1) / kSuper;
+    max_sb = std::max<uint64_t>(max_sb, (px + kSuper - 1) / kSuper);  // superblocks that hold pixels (coded pixels are no more)
     out_used += im.out_cap;
     if (out_used > out_cap) return VP8L_ERR_NO_MEMORY;
     if (sb_total > 0x3fffffffu) return VP8L_ERR_NO_MEMORY;
@@ -2906,7 +2995,7 @@ static int vp8l_encoder_encode_device_impl(vp8l_encoder *e, size_t n, const uint
     ext.rows = e->x_rows.as<uint32_t>();
   }
   rc_launch = launch_encode_kernels(s, B, nl, (uint32_t)sb_total, pred, cross, e->match_mode, d_out, e->ev, e->standard ? 1u : 0u, &ext,
-                                    (uint32_t)e->meta_bits);
+                                    (uint32_t)e->meta_bits, (uint32_t)max_sb);
   if (rc_launch != VP8L_OK) return rc_launch;
   if (!hip_ok(hipMemcpyAsync(e->states.data(), st, nl * sizeof(EncState), hipMemcpyDeviceToHost, s), "download state")) return VP8L_ERR_HIP;
   if (!hip_ok(hipStreamSynchronize(s), "encode batch")) return VP8L_ERR_HIP;
@@ -3234,7 +3323,7 @@ extern "C" int vp8l_encode_device_noalloc(int device, void *stream, const uint32
   uint64_t *result = reinterpret_cast<uint64_t *>(ws + kNaResult);
   const uint32_t sb_total = (uint32_t)((px + kTailPad + kSuper - 1) / kSuper);
   hipLaunchKernelGGL(k_noalloc_setup, dim3(1), dim3(64), 0, s, B.imgs, B.sbf, d_argb, width, height, (uint64_t)vp8l_encode_bound(width, height), sb_total);
-  rc = launch_encode_kernels(s, B, 1, sb_total, 0, 0, 0, d_out, nullptr);
+  rc = launch_encode_kernels(s, B, 1, sb_total, 0, 0, 0, d_out, nullptr, 0, nullptr, 0, (uint32_t)((px + kSuper - 1) / kSuper));
   if (rc != VP8L_OK) return rc;
   hipLaunchKernelGGL(k_noalloc_result, dim3(1), dim3(64), 0, s, B.st, result, d_result);
   if (!hip_ok(hipGetLastError(), "kernel launch")) return VP8L_ERR_HIP;
