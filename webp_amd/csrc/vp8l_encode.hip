@@ -2285,19 +2285,40 @@ __global__ __launch_bounds__(256) void k_scan(const EncImage *__restrict__ imgs,
   uint32_t *out32 = reinterpret_cast<uint32_t *>(out + im.out_off);
   const uint64_t hdr_word = s.hdr_bits >> 5;
   uint64_t running = s.hdr_bits;
-  for (uint32_t base = 0; base < nunits; base += 256) {
-    const uint32_t u = base + tid;
-    const uint32_t v = u < nunits ? unit_bits[unit0 + u] : 0u;
-    const uint32_t incl = wave_incl_scan_u32(v, (int)lane);
+  // kScanPer consecutive units a thread and round (one image of 16383 x 16383 has 65528 units: one unit a thread, the 256 rounds
+  // with their loads and barriers took 0.16 ms)
+  constexpr uint32_t kScanPer = 8;
+  for (uint32_t base = 0; base < nunits; base += 256 * kScanPer) {
+    const uint32_t u0 = base + tid * kScanPer;
+    uint32_t v[kScanPer];
+    if (u0 + kScanPer <= nunits) {  // (unit0 is a multiple of 4 and so is u0: 16-byte loads)
+#pragma unroll
+      for (uint32_t j = 0; j < kScanPer; j += 4) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(unit_bits + unit0 + u0 + j);
+        v[j] = q.x; v[j + 1] = q.y; v[j + 2] = q.z; v[j + 3] = q.w;
+      }
+    } else {
+#pragma unroll
+      for (uint32_t j = 0; j < kScanPer; j++) v[j] = u0 + j < nunits ? unit_bits[unit0 + u0 + j] : 0u;
+    }
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kScanPer; j++) mine += v[j];  // (a thread's units hold less than 2^32 bits: 8 x 4096 tokens of at most 75 bits)
+    const uint32_t incl = wave_incl_scan_u32(mine, (int)lane);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     uint64_t before = running;
     for (uint32_t k = 0; k < wave; k++) before += wsum[k];
     const uint64_t total = (uint64_t)wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (u < nunits) {
-      const uint64_t off = before + incl - v;
-      unit_off[unit0 + u] = off;
-      if (u > 0 && (off >> 5) > hdr_word) out32[off >> 5] = 0;
+    uint64_t off = before + incl - mine;
+#pragma unroll
+    for (uint32_t j = 0; j < kScanPer; j++) {
+      const uint32_t u = u0 + j;
+      if (u < nunits) {
+        unit_off[unit0 + u] = off;
+        if (u > 0 && (off >> 5) > hdr_word) out32[off >> 5] = 0;
+      }
+      off += v[j];
     }
     running += total;
     __syncthreads();
