@@ -2803,7 +2803,7 @@ static int launch_encode_kernels(hipStream_t s, const EncBuffers &B, uint32_t nl
                      match_mode == 0 ? B.dense : (const uint8_t *)nullptr);
   mark(3);
   hipLaunchKernelGGL(k_parse_exits, dim3(gsb), dim3(128), 0, s, B.imgs, B.st, B.sbf, nl, B.adv8, B.sx);
-  if (max_sb_per_image > kChainSerialMax && max_sb_per_image <= kChainMaxRounds * kChainRound) {
+  if (max_sb_per_image > kChainSerialMax && max_sb_per_image <= kChainMaxRounds * kChainRound && nl <= 65535u) {  // (a grid's second dimension)
     // the maps of the rounds lie where the token-start bits will be (k_parse_mark writes those after this, every word of them)
     uint8_t *rmap = reinterpret_cast<uint8_t *>(B.flags);
     const dim3 grid((max_sb_per_image + kChainRound - 1) / kChainRound, nl);
