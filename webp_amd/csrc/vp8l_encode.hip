@@ -2157,6 +2157,7 @@ __global__ __launch_bounds__(256) void k_entropy_header(const EncImage *__restri
     uint32_t w = code_unwritten(&sh.sub.tables, i) ? 0u : sh.sub.tables.len[i];
     const uint32_t prefix = c == (uint32_t)kGreen && sym >= 256 ? sym - 256 : c == (uint32_t)kDist ? sym : 0u;
     if (prefix >= 4) w += (prefix - 2) >> 1;  // extra bits of a prefix symbol (lz77.cpp:89-102)
+    if (sym >= (uint32_t)alphabet_size((int)c)) w = 0;  // (places of the row that no symbol has)
     sh.sub.tables.wbits[i] = (uint8_t)w;
   }
   __syncthreads();
@@ -2316,7 +2317,9 @@ __global__ __launch_bounds__(256) void k_scan(const EncImage *__restrict__ imgs,
       const uint32_t u = u0 + j;
       if (u < nunits) {
         unit_off[unit0 + u] = off;
-        if (u > 0 && (off >> 5) > hdr_word) out32[off >> 5] = 0;
+        // (inside the image's output only: a stream that does not fit fails below, and unit sizes that are not what they should
+        // be must not turn into stores elsewhere)
+        if (u > 0 && (off >> 5) > hdr_word && (off >> 3) + 4 <= im.out_cap) out32[off >> 5] = 0;
       }
       off += v[j];
     }
@@ -2325,7 +2328,7 @@ __global__ __launch_bounds__(256) void k_scan(const EncImage *__restrict__ imgs,
   }
   if (tid == 0) {
     s.total_bits = running;
-    if ((running >> 5) > hdr_word) out32[running >> 5] = 0;
+    if ((running >> 5) > hdr_word && (running >> 3) + 4 <= im.out_cap) out32[running >> 5] = 0;
     if ((running + 7) / 8 + 8 > im.out_cap) s.status = VP8L_ERR_NO_MEMORY;
     // standard dialect: the first 32 bits are the RIFF chunk size, the bytes that follow them (the reference leaves zero, vp8l.h:461)
     if (standard) out32[0] = (uint32_t)((running + 7) / 8 - 4);
